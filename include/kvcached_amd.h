@@ -1,0 +1,188 @@
+/* kvcached_amd.h — C ABI of libkvcached_amd.so, the MI355X-native elastic KV-cache VMM.
+ *
+ * This is the drop-in boundary for the reference's hot path. The reference exposes the
+ * path as a pybind11 module `kvcached.vmm_ops` (csrc/torch_bindings.cpp:182-258); every
+ * entry point below is what that module's functions/methods bind, one C symbol per
+ * Python-visible function, with plain pointers and sizes only (no torch, no C++ types).
+ * kvcached_amd/csrc/vmm_ops.cpp is the pybind11 layer that re-creates the exact
+ * `vmm_ops` Python surface on top of these symbols; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - return 0 / non-negative on success, a negative KVC_E_* code on failure;
+ *     kvc_last_error() returns the message for the calling thread.
+ *   - all functions are thread-safe unless noted; none requires the Python GIL.
+ *   - offsets and sizes are bytes; ids are int64_t like the reference's page_id_t.
+ *   - device strings: "cuda", "cuda:N", "hip:N" (PyTorch-ROCm spelling) or "cpu".
+ *     "cpu" is the reference's own host device (csrc/ftensor.cpp:40-44, csrc/page.cpp:28-37):
+ *     anonymous mmap, map/unmap are bookkeeping only. It is never selected implicitly and
+ *     the HIP kernels refuse it (KVC_E_NO_GPU).
+ */
+#ifndef KVCACHED_AMD_H
+#define KVCACHED_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVC_ABI_VERSION 1
+
+enum {
+  KVC_OK = 0,
+  KVC_E_INVALID = -1,  /* bad argument / bad state (reference: LOGGER(ERROR)+false or abort) */
+  KVC_E_GPU = -2,      /* a HIP runtime call failed (reference: CHECK_GPU -> abort, csrc/inc/gpu_vmm.hpp:37-45) */
+  KVC_E_NO_PAGES = -3, /* "No free pages left" (csrc/page_allocator.cpp:201) */
+  KVC_E_RUNTIME = -4,  /* any other std::runtime_error of the reference */
+  KVC_E_NO_GPU = -5,   /* a GPU-only entry point was called on the "cpu" device / without a GPU */
+  KVC_E_CALLBACK = -6  /* a broadcast callback reported failure */
+};
+
+const char *kvc_last_error(void);
+int kvc_abi_version(void);
+
+/* ------------------------------------------------------------------ allocator lifecycle
+ * replaces kvcached.vmm_ops.{init_kvcached, shutdown_kvcached, create_kv_tensors,
+ * kv_tensors_created, map_to_kv_tensors, unmap_from_kv_tensors}
+ * (csrc/torch_bindings.cpp:20-58,185-198 -> csrc/allocator.cpp:72-257). */
+
+/* page_size 0 = keep default 2 MiB; must be a multiple of 2 MiB (allocator.cpp:81-90). */
+int kvc_init(const char *dev_str, size_t page_size, int contiguous_layout);
+int kvc_shutdown(void);
+
+/* Reserves VA and (in compat mode) backfills it with the shared zero page.
+ * On return out_ptrs[i]/out_nbytes[i] describe tensor i (num_layers tensors, or ONE in
+ * contiguous layout); *inout_count is capacity on entry, tensor count on exit.
+ * dtype_size must be 1/2/4/8 (csrc/inc/impl/torch_utils.ipp:32-46). */
+int kvc_create_kv_tensors(size_t size, size_t dtype_size, const char *dev_str, int64_t num_layers,
+                          int64_t num_kv_buffers, int64_t group_id, int unified_pool, void **out_ptrs,
+                          size_t *out_nbytes, int64_t *inout_count);
+int kvc_kv_tensors_created(int64_t group_id); /* 1 / 0 / <0 */
+/* Device chosen by kvc_init: *is_gpu 0 for "cpu"; *index is the resolved HIP device ordinal. */
+int kvc_get_device(int *is_gpu, int *index);
+
+/* The batched hot path. One call backs every (layer x K/V) slot of every offset:
+ * physical handles come from the per-device pool, hipMemMap + ranged hipMemSetAccess,
+ * then the zero_fill_pages kernel on the allocator's stream, overlapped with the
+ * remaining driver calls; returns after the fill has completed. */
+int kvc_map_to_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
+int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
+
+/* Runtime knobs (also read once from the environment at kvc_init):
+ *   KVC_OPT_ZERO_BACKFILL  1 = every unbacked VA page aliases one shared zero page, as the
+ *                              reference does (csrc/ftensor.cpp:160-176); 0 = leave unbacked
+ *                              VA unmapped (faster map/unmap, reads of unbacked VA fault).
+ *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
+ *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
+ *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py). */
+enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4 };
+int kvc_set_option(int opt, int64_t value);
+int64_t kvc_get_option(int opt);
+
+/* Counters since kvc_init / last reset. */
+typedef struct kvc_stats {
+  int64_t pages_mapped, pages_unmapped;       /* physical slots */
+  int64_t handles_created, handles_released, handles_reused;
+  int64_t map_calls, unmap_calls;             /* kvc_(un)map_to_kv_tensors invocations */
+  int64_t map_ns, unmap_ns;                   /* host wall time inside them */
+  int64_t fill_launches, fill_bytes;          /* zero_fill_pages */
+  double fill_ms;                             /* sum of event-timed kernel durations (profile on) */
+  int64_t compact_launches, compact_bytes;    /* compact_blocks: bytes read + written */
+  double compact_ms;
+} kvc_stats_t;
+int kvc_get_stats(kvc_stats_t *out);
+int kvc_reset_stats(void);
+
+/* hipMemGetInfo of the allocator's device; kvc_set_mem_info_override(free,total) replaces
+ * the reading (tests and the "cpu" device), (0,0) removes the override. */
+int kvc_mem_get_info(size_t *free_bytes, size_t *total_bytes);
+int kvc_set_mem_info_override(size_t free_bytes, size_t total_bytes);
+
+/* ------------------------------------------------------------------ InternalPage
+ * replaces vmm_ops.InternalPage (torch_bindings.cpp:242-257 -> page_allocator.cpp:40-100). */
+typedef struct kvc_page kvc_page_t;
+kvc_page_t *kvc_page_new(int64_t page_id, int64_t page_size);
+void kvc_page_delete(kvc_page_t *p);
+int64_t kvc_page_id(const kvc_page_t *p);
+int64_t kvc_page_size(const kvc_page_t *p);
+void kvc_page_init(kvc_page_t *p, int64_t block_mem_size);
+int64_t kvc_page_alloc(kvc_page_t *p, int64_t num_blocks, int64_t *out); /* count, or KVC_E_RUNTIME "Not enough free blocks in page" */
+void kvc_page_free(kvc_page_t *p, int64_t block_id);
+void kvc_page_free_batch(kvc_page_t *p, const int64_t *block_ids, size_t n);
+int kvc_page_empty(const kvc_page_t *p);
+int kvc_page_full(const kvc_page_t *p);
+int64_t kvc_page_num_free_blocks(const kvc_page_t *p);
+int64_t kvc_page_get_free_blocks(const kvc_page_t *p, int64_t *out, int64_t cap); /* returns count; copies if cap suffices */
+void kvc_page_get_block_range(int64_t page_id, int64_t page_size, int64_t block_mem_size, int64_t *start, int64_t *end);
+int64_t kvc_page_get_num_blocks(int64_t page_size, int64_t block_mem_size);
+
+/* ------------------------------------------------------------------ PageAllocator
+ * replaces vmm_ops.PageAllocator (torch_bindings.cpp:201-239 -> page_allocator.cpp:103-782). */
+typedef struct kvc_page_allocator kvc_page_allocator_t;
+/* returns nonzero to report failure (raised as "Failed to map page N: ..." by alloc_page) */
+typedef int (*kvc_broadcast_cb)(void *user, int64_t world_size, const int64_t *offsets, size_t n);
+typedef int (*kvc_bool_cb)(void *user);
+
+kvc_page_allocator_t *kvc_pa_new(int64_t num_layers, int64_t mem_size_per_layer, int64_t page_size,
+                                 int64_t world_size, int64_t pp_rank, int async_sched, int contiguous_layout,
+                                 int enable_page_prealloc, int64_t num_kv_buffers, int64_t group_id,
+                                 const char *ipc_name);
+void kvc_pa_delete(kvc_page_allocator_t *pa);
+int kvc_pa_start_prealloc_thread(kvc_page_allocator_t *pa);
+int kvc_pa_stop_prealloc_thread(kvc_page_allocator_t *pa);
+int64_t kvc_pa_alloc_page(kvc_page_allocator_t *pa); /* page id, or KVC_E_* */
+int kvc_pa_free_page(kvc_page_allocator_t *pa, int64_t page_id);
+int kvc_pa_free_pages(kvc_page_allocator_t *pa, const int64_t *page_ids, size_t n);
+int kvc_pa_resize(kvc_page_allocator_t *pa, int64_t new_mem_size); /* 1 / 0 / <0 */
+int kvc_pa_trim(kvc_page_allocator_t *pa);
+int kvc_pa_reset_free_page_order(kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_num_free_pages(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_num_inuse_pages(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_num_total_pages(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_num_reserved_pages(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_avail_physical_pages(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_check_and_get_resize_target(const kvc_page_allocator_t *pa, int64_t current_mem_size);
+int64_t kvc_pa_get_resize_target(const kvc_page_allocator_t *pa);
+int64_t kvc_pa_get_page_id(const kvc_page_allocator_t *pa, int64_t block_id, int64_t block_mem_size);
+/* group_indices_by_page, flattened in the ITERATION ORDER of the reference's
+ * std::unordered_map (page_allocator.cpp:471-498): keys[k], counts[k], values concatenated.
+ * keys/counts/values need room for n entries. Returns the number of groups. */
+int64_t kvc_pa_group_indices_by_page(const kvc_page_allocator_t *pa, const int64_t *indices, size_t n,
+                                     int64_t block_mem_size, int64_t *keys, int64_t *counts, int64_t *values);
+int kvc_pa_set_broadcast_map_callback(kvc_page_allocator_t *pa, kvc_broadcast_cb cb, void *user);
+int kvc_pa_set_broadcast_unmap_callback(kvc_page_allocator_t *pa, kvc_broadcast_cb cb, void *user);
+int kvc_pa_set_should_use_worker_ipc_callback(kvc_page_allocator_t *pa, kvc_bool_cb cb, void *user);
+/* Introspection used by tests and the compaction planner: which = 0 free, 1 reserved, 2 reclaimed. */
+int64_t kvc_pa_get_page_list(const kvc_page_allocator_t *pa, int which, int64_t *out, int64_t cap);
+const char *kvc_pa_ipc_name(const kvc_page_allocator_t *pa);
+
+/* ------------------------------------------------------------------ HIP kernels (north-star additions;
+ * no reference symbol — SURVEY.md §8 row a-N). `stream` is a hipStream_t or NULL for the
+ * library's own stream; launches are asynchronous unless `sync` is nonzero. */
+
+/* zero_fill_pages: each of the n page base pointers (device VAs, host array) gets page_bytes
+ * of zeros. page_bytes must be a multiple of 64 KiB; pointers 64 KiB-aligned. */
+int kvc_zero_fill_pages(void *const *page_ptrs, size_t n, size_t page_bytes, void *stream, int sync);
+
+/* compact_blocks: for every region base (one per layer x K/V buffer; device VAs, host array) and
+ * every move m: copy block_bytes from base + src_block[m]*block_bytes to base + dst_block[m]*block_bytes.
+ * block_bytes must be a multiple of 16; src and dst block sets must be disjoint. */
+int kvc_compact_blocks(void *const *region_bases, size_t n_regions, const int64_t *src_blocks,
+                       const int64_t *dst_blocks, size_t n_moves, size_t block_bytes, void *stream, int sync);
+
+/* Region bases of a group's KV tensors in map order (layer-major, K then V), for compact_blocks.
+ * Returns the count; copies if cap suffices. */
+int64_t kvc_get_region_bases(int64_t group_id, void **out, int64_t cap);
+
+/* ------------------------------------------------------------------ TP shared pool (north-star addition;
+ * the reference has no memory sharing — kvcached/tp_ipc_util.py only broadcasts offsets).
+ * Rank 0 backs slots with exportable handles and exports one POSIX fd per slot; peers import
+ * the fds (received over SCM_RIGHTS) and map them at the same offsets. */
+int kvc_export_mapped_slots(const int64_t *offsets, size_t n, int64_t group_id, int *out_fds, int64_t cap); /* returns fd count */
+int kvc_map_imported_slots(const int64_t *offsets, size_t n, int64_t group_id, const int *fds, size_t n_fds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVCACHED_AMD_H */

@@ -1,0 +1,223 @@
+"""ctypes binding of the C ABI (include/kvcached_amd.h) — the same symbols the pybind11 module
+`vmm_ops` sits on. Used for the entry points that have no counterpart in the reference's
+`vmm_ops` surface (HIP kernels, statistics, options, shared-pool export/import) and by the
+tests/bench, which drive the hot path through the C ABI directly.
+
+There is no fallback: if libkvcached_amd.so is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvcached_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: build it with `python -m kvcached_amd.build` "
+                      "(hipcc --offload-arch=gfx950). kvcached_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, KVC_E_CALLBACK = 0, -1, -2, -3, -4, -5, -6
+OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE = 1, 2, 3, 4
+OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
+
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_VPP = ctypes.POINTER(ctypes.c_void_p)
+_INTP = ctypes.POINTER(ctypes.c_int)
+_SZP = ctypes.POINTER(ctypes.c_size_t)
+
+BROADCAST_CB = ctypes.CFUNCTYPE(_int, _vp, _i64, _I64P, _sz)
+BOOL_CB = ctypes.CFUNCTYPE(_int, _vp)
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("pages_mapped", _i64), ("pages_unmapped", _i64),
+                ("handles_created", _i64), ("handles_released", _i64), ("handles_reused", _i64),
+                ("map_calls", _i64), ("unmap_calls", _i64), ("map_ns", _i64), ("unmap_ns", _i64),
+                ("fill_launches", _i64), ("fill_bytes", _i64), ("fill_ms", ctypes.c_double),
+                ("compact_launches", _i64), ("compact_bytes", _i64), ("compact_ms", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# symbol -> (restype, argtypes); this table is also what tests/test_c_abi.py checks against the header
+SIGNATURES = {
+    "kvc_last_error": (ctypes.c_char_p, []),
+    "kvc_abi_version": (_int, []),
+    "kvc_init": (_int, [ctypes.c_char_p, _sz, _int]),
+    "kvc_shutdown": (_int, []),
+    "kvc_create_kv_tensors": (_int, [_sz, _sz, ctypes.c_char_p, _i64, _i64, _i64, _int, _VPP, _SZP, _I64P]),
+    "kvc_kv_tensors_created": (_int, [_i64]),
+    "kvc_get_device": (_int, [_INTP, _INTP]),
+    "kvc_map_to_kv_tensors": (_int, [_I64P, _sz, _i64]),
+    "kvc_unmap_from_kv_tensors": (_int, [_I64P, _sz, _i64]),
+    "kvc_set_option": (_int, [_int, _i64]),
+    "kvc_get_option": (_i64, [_int]),
+    "kvc_get_stats": (_int, [ctypes.POINTER(Stats)]),
+    "kvc_reset_stats": (_int, []),
+    "kvc_mem_get_info": (_int, [_SZP, _SZP]),
+    "kvc_set_mem_info_override": (_int, [_sz, _sz]),
+    "kvc_page_new": (_vp, [_i64, _i64]),
+    "kvc_page_delete": (None, [_vp]),
+    "kvc_page_id": (_i64, [_vp]),
+    "kvc_page_size": (_i64, [_vp]),
+    "kvc_page_init": (None, [_vp, _i64]),
+    "kvc_page_alloc": (_i64, [_vp, _i64, _I64P]),
+    "kvc_page_free": (None, [_vp, _i64]),
+    "kvc_page_free_batch": (None, [_vp, _I64P, _sz]),
+    "kvc_page_empty": (_int, [_vp]),
+    "kvc_page_full": (_int, [_vp]),
+    "kvc_page_num_free_blocks": (_i64, [_vp]),
+    "kvc_page_get_free_blocks": (_i64, [_vp, _I64P, _i64]),
+    "kvc_page_get_block_range": (None, [_i64, _i64, _i64, _I64P, _I64P]),
+    "kvc_page_get_num_blocks": (_i64, [_i64, _i64]),
+    "kvc_pa_new": (_vp, [_i64, _i64, _i64, _i64, _i64, _int, _int, _int, _i64, _i64, ctypes.c_char_p]),
+    "kvc_pa_delete": (None, [_vp]),
+    "kvc_pa_start_prealloc_thread": (_int, [_vp]),
+    "kvc_pa_stop_prealloc_thread": (_int, [_vp]),
+    "kvc_pa_alloc_page": (_i64, [_vp]),
+    "kvc_pa_free_page": (_int, [_vp, _i64]),
+    "kvc_pa_free_pages": (_int, [_vp, _I64P, _sz]),
+    "kvc_pa_resize": (_int, [_vp, _i64]),
+    "kvc_pa_trim": (_int, [_vp]),
+    "kvc_pa_reset_free_page_order": (_int, [_vp]),
+    "kvc_pa_get_num_free_pages": (_i64, [_vp]),
+    "kvc_pa_get_num_inuse_pages": (_i64, [_vp]),
+    "kvc_pa_get_num_total_pages": (_i64, [_vp]),
+    "kvc_pa_get_num_reserved_pages": (_i64, [_vp]),
+    "kvc_pa_get_avail_physical_pages": (_i64, [_vp]),
+    "kvc_pa_check_and_get_resize_target": (_i64, [_vp, _i64]),
+    "kvc_pa_get_resize_target": (_i64, [_vp]),
+    "kvc_pa_get_page_id": (_i64, [_vp, _i64, _i64]),
+    "kvc_pa_group_indices_by_page": (_i64, [_vp, _I64P, _sz, _i64, _I64P, _I64P, _I64P]),
+    "kvc_pa_set_broadcast_map_callback": (_int, [_vp, BROADCAST_CB, _vp]),
+    "kvc_pa_set_broadcast_unmap_callback": (_int, [_vp, BROADCAST_CB, _vp]),
+    "kvc_pa_set_should_use_worker_ipc_callback": (_int, [_vp, BOOL_CB, _vp]),
+    "kvc_pa_get_page_list": (_i64, [_vp, _int, _I64P, _i64]),
+    "kvc_pa_ipc_name": (ctypes.c_char_p, [_vp]),
+    "kvc_zero_fill_pages": (_int, [_VPP, _sz, _sz, _vp, _int]),
+    "kvc_compact_blocks": (_int, [_VPP, _sz, _I64P, _I64P, _sz, _sz, _vp, _int]),
+    "kvc_get_region_bases": (_i64, [_i64, _VPP, _i64]),
+    "kvc_export_mapped_slots": (_int, [_I64P, _sz, _i64, _INTP, _i64]),
+    "kvc_map_imported_slots": (_int, [_I64P, _sz, _i64, _INTP, _sz]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not match the header
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+class KvcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg or f"kvcached_amd error {code}")
+        self.code = code
+
+
+def last_error() -> str:
+    return (lib.kvc_last_error() or b"").decode()
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise KvcError(rc, last_error())
+    return rc
+
+
+def i64_array(vals: Sequence[int]):
+    return (ctypes.c_int64 * max(1, len(vals)))(*vals)
+
+
+def ptr_array(vals: Sequence[int]):
+    return (ctypes.c_void_p * max(1, len(vals)))(*vals)
+
+
+# ------------------------------------------------------------------ convenience wrappers
+def init(dev: str, page_size: int = 0, contiguous_layout: bool = False) -> None:
+    check(lib.kvc_init(dev.encode(), page_size, int(contiguous_layout)))
+
+
+def shutdown() -> None:
+    check(lib.kvc_shutdown())
+
+
+def create_kv_tensors(size: int, dtype_size: int, dev: str, num_layers: int, num_kv_buffers: int = 2,
+                      group_id: int = 0, unified_pool: bool = False) -> List[Tuple[int, int]]:
+    """Returns [(device_ptr, nbytes), ...]."""
+    cap = max(1, num_layers)
+    ptrs, nbytes, cnt = (ctypes.c_void_p * cap)(), (ctypes.c_size_t * cap)(), ctypes.c_int64(cap)
+    check(lib.kvc_create_kv_tensors(size, dtype_size, dev.encode(), num_layers, num_kv_buffers, group_id,
+                                    int(unified_pool), ptrs, nbytes, ctypes.byref(cnt)))
+    return [(int(ptrs[i] or 0), int(nbytes[i])) for i in range(cnt.value)]
+
+
+def map_to_kv_tensors(offsets: Sequence[int], group_id: int = 0) -> None:
+    check(lib.kvc_map_to_kv_tensors(i64_array(offsets), len(offsets), group_id))
+
+
+def unmap_from_kv_tensors(offsets: Sequence[int], group_id: int = 0) -> None:
+    check(lib.kvc_unmap_from_kv_tensors(i64_array(offsets), len(offsets), group_id))
+
+
+def set_option(opt: int, value: int) -> None:
+    check(lib.kvc_set_option(opt, value))
+
+
+def get_option(opt: int) -> int:
+    return lib.kvc_get_option(opt)
+
+
+def get_stats() -> dict:
+    s = Stats()
+    check(lib.kvc_get_stats(ctypes.byref(s)))
+    return s.as_dict()
+
+
+def reset_stats() -> None:
+    check(lib.kvc_reset_stats())
+
+
+def mem_get_info() -> Tuple[int, int]:
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib.kvc_mem_get_info(ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
+
+
+def set_mem_info_override(free_bytes: int, total_bytes: int) -> None:
+    check(lib.kvc_set_mem_info_override(free_bytes, total_bytes))
+
+
+def zero_fill_pages(page_ptrs: Sequence[int], page_bytes: int, stream: int = 0, sync: bool = True) -> None:
+    """Zero `page_bytes` at each device pointer with the gfx950 fill kernel."""
+    check(lib.kvc_zero_fill_pages(ptr_array(page_ptrs), len(page_ptrs), page_bytes, stream or None, int(sync)))
+
+
+def compact_blocks(region_bases: Sequence[int], src_blocks: Sequence[int], dst_blocks: Sequence[int],
+                   block_bytes: int, stream: int = 0, sync: bool = True) -> None:
+    """In every region copy block src[m] onto block dst[m] (HIP kernel, LDS-staged)."""
+    if len(src_blocks) != len(dst_blocks):
+        raise ValueError("src_blocks and dst_blocks differ in length")
+    check(lib.kvc_compact_blocks(ptr_array(region_bases), len(region_bases), i64_array(src_blocks),
+                                 i64_array(dst_blocks), len(src_blocks), block_bytes, stream or None, int(sync)))
+
+
+def get_region_bases(group_id: int = 0) -> List[int]:
+    n = check(lib.kvc_get_region_bases(group_id, None, 0))
+    buf = (ctypes.c_void_p * max(1, n))()
+    check(lib.kvc_get_region_bases(group_id, buf, n))
+    return [int(buf[i] or 0) for i in range(n)]
+
+
+def export_mapped_slots(offsets: Sequence[int], group_id: int = 0) -> List[int]:
+    n = check(lib.kvc_export_mapped_slots(i64_array(offsets), len(offsets), group_id, None, 0))
+    fds = (ctypes.c_int * max(1, n))()
+    k = check(lib.kvc_export_mapped_slots(i64_array(offsets), len(offsets), group_id, fds, n))
+    return [int(fds[i]) for i in range(k)]
+
+
+def map_imported_slots(offsets: Sequence[int], fds: Sequence[int], group_id: int = 0) -> None:
+    arr = (ctypes.c_int * max(1, len(fds)))(*fds)
+    check(lib.kvc_map_imported_slots(i64_array(offsets), len(offsets), group_id, arr, len(fds)))

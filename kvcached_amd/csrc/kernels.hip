@@ -1,0 +1,188 @@
+// kernels.hip — the two device kernels of the path, written for gfx950 (CDNA4) only.
+//
+// Both are pure byte movers and HBM-bound (no MFMA: there is no contraction anywhere on this
+// path). What matters on MI355X, and what the code below does:
+//   * every wave-instruction touches 64 lanes x 16 B = 1 KiB of contiguous memory
+//     (global_store_dwordx4 / global_load_dwordx4 / global_load_lds_dwordx4);
+//   * one workgroup per 64 KiB slab (fill) or per <=32 KiB tile (compaction) and NO grid-stride
+//     loop: with 256 CUs in 8 XCDs a batch is tens of thousands of workgroups, and the probe
+//     showed short-lived workgroups beating a persistent 2048-block grid (6.9 vs 6.1 TB/s);
+//   * the page / region tables ride in the kernarg segment (scalar loads, no table in HBM,
+//     no extra copy on the launch path);
+//   * consecutive workgroups (dealt round-robin over the 8 XCDs) take consecutive slabs, so
+//     each XCD's L2 streams a disjoint 1/8 of every page and nothing is written twice.
+//
+// Algorithmic bytes: zero_fill_pages writes page_bytes per page (2 097 152 B
+// for a 2 MiB page) and reads nothing; compact_blocks reads + writes block_bytes per
+// (region, move) = 2 x block_bytes x n_regions per moved block.
+
+#include "kernels.hpp"
+
+namespace kvc {
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+struct PageTable {
+  void *p[kMaxPtrsPerLaunch];
+};
+
+// ---------------------------------------------------------------------------- zero_fill_pages
+// THREADS x STORES x 16 B == 64 KiB. Lane l of wave w stores at slab + (i*THREADS + tid)*16:
+// each store instruction of a wave covers one aligned 1 KiB line group.
+template <int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void zero_fill_pages_kernel(PageTable pages, unsigned slabs_per_page) {
+  constexpr int STORES = (int)(kFillSlabBytes / 16 / THREADS);
+  const unsigned page = blockIdx.x / slabs_per_page; // wave-uniform -> scalar kernarg load
+  const unsigned slab = blockIdx.x - page * slabs_per_page;
+  v4u *dst = reinterpret_cast<v4u *>(static_cast<char *>(pages.p[page]) + (size_t)slab * kFillSlabBytes) + threadIdx.x;
+  const v4u z = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < STORES; ++i) {
+    if (NT)
+      __builtin_nontemporal_store(z, dst + i * THREADS);
+    else
+      dst[i * THREADS] = z;
+  }
+}
+
+hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, hipStream_t stream, int variant) {
+  if (n <= 0) return hipSuccess;
+  if (n > kMaxPtrsPerLaunch || page_bytes == 0 || page_bytes % kFillSlabBytes != 0) return hipErrorInvalidValue;
+  PageTable t;
+  for (int i = 0; i < n; ++i) {
+    if (reinterpret_cast<uintptr_t>(pages[i]) % 16 != 0) return hipErrorInvalidValue;
+    t.p[i] = pages[i];
+  }
+  const unsigned slabs = (unsigned)(page_bytes / kFillSlabBytes);
+  const size_t grid = (size_t)slabs * (size_t)n;
+  if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+  switch (variant) {
+  case 1:
+    zero_fill_pages_kernel<256, false><<<dim3((unsigned)grid), dim3(256), 0, stream>>>(t, slabs);
+    break;
+  case 2:
+    zero_fill_pages_kernel<512, true><<<dim3((unsigned)grid), dim3(512), 0, stream>>>(t, slabs);
+    break;
+  case 3:
+    zero_fill_pages_kernel<1024, false><<<dim3((unsigned)grid), dim3(1024), 0, stream>>>(t, slabs);
+    break;
+  default:
+    zero_fill_pages_kernel<512, false><<<dim3((unsigned)grid), dim3(512), 0, stream>>>(t, slabs);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- compact_blocks
+struct CompactArgs {
+  void *base[kMaxRegionsPerLaunch];
+  int64_t src[kMaxMovesPerLaunch];
+  int64_t dst[kMaxMovesPerLaunch];
+};
+static_assert(sizeof(CompactArgs) <= 3072, "kernarg segment budget");
+
+static constexpr int kCompactThreads = 256;          // 4 waves
+static constexpr int kCompactTile = 16 * 1024;       // bytes per workgroup: 4 waves x 4 x 1 KiB
+static constexpr int kPiece = 1024;                  // one wave-instruction
+static constexpr int kPiecesPerWave = kCompactTile / kPiece / (kCompactThreads / 64);
+
+// Variant 0 — LDS-staged. Each wave DMAs its four 1 KiB pieces global->LDS
+// (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane*16), waits
+// for its own DMAs (vmcnt), reads them back with ds_read_b128 and streams them out with
+// global_store_dwordx4. A wave only ever reads LDS bytes it loaded itself, so no barrier is
+// needed; 16 KiB of LDS per workgroup lets 8+ workgroups share a CU (>=128 KiB in flight).
+__global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(CompactArgs a, unsigned n_moves,
+                                                                              unsigned tiles_per_block,
+                                                                              unsigned block_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[kCompactTile];
+  const unsigned t = blockIdx.x % tiles_per_block;
+  const unsigned m = (blockIdx.x / tiles_per_block) % n_moves;
+  const unsigned r = blockIdx.x / (tiles_per_block * n_moves);
+  const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
+  char *dst = static_cast<char *>(a.base[r]) + a.dst[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
+  const unsigned remain = block_bytes - t * kCompactTile; // bytes of this tile that exist (>= 16)
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool full = remain >= (unsigned)kCompactTile; // wave-uniform: every tile but a ragged last one
+  const unsigned limit = full ? (unsigned)kCompactTile : remain;
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) {
+    const unsigned off = (wave * kPiecesPerWave + i) * kPiece + lane * 16;
+    if (full || off < limit)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                       (__attribute__((address_space(3))) void *)(tile +
+                                                                                  (wave * kPiecesPerWave + i) * kPiece),
+                                       16, 0, 0);
+  }
+  // The DMA writes LDS behind the compiler's back: wait for this wave's pieces by hand.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (full) {
+    v4u v[kPiecesPerWave];
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      v[i] = *reinterpret_cast<const v4u *>(tile + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      *reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16) = v[i];
+  } else {
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      const unsigned off = (wave * kPiecesPerWave + i) * kPiece + lane * 16;
+      if (off < limit) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(tile + off);
+    }
+  }
+}
+
+// Variant 1 — register-staged: all loads of a lane in flight first, then the stores.
+__global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(CompactArgs a, unsigned n_moves,
+                                                                              unsigned tiles_per_block,
+                                                                              unsigned block_bytes) {
+  const unsigned t = blockIdx.x % tiles_per_block;
+  const unsigned m = (blockIdx.x / tiles_per_block) % n_moves;
+  const unsigned r = blockIdx.x / (tiles_per_block * n_moves);
+  const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
+  char *dst = static_cast<char *>(a.base[r]) + a.dst[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
+  const unsigned remain = block_bytes - t * kCompactTile;
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (remain >= (unsigned)kCompactTile) { // full tile: every load in flight before the first store
+    v4u v[kPiecesPerWave];
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      v[i] = *reinterpret_cast<const v4u *>(src + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i)
+      *reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16) = v[i];
+  } else {
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      const unsigned off = (wave * kPiecesPerWave + i) * kPiece + lane * 16;
+      if (off < remain) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(src + off);
+    }
+  }
+}
+
+hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
+                                 size_t block_bytes, hipStream_t stream, int variant) {
+  if (n_regions <= 0 || n_moves <= 0) return hipSuccess;
+  if (n_regions > kMaxRegionsPerLaunch || n_moves > kMaxMovesPerLaunch || block_bytes == 0 || block_bytes % 16 != 0 ||
+      block_bytes > 0x7fffffffull)
+    return hipErrorInvalidValue;
+  CompactArgs a;
+  for (int i = 0; i < n_regions; ++i) {
+    if (reinterpret_cast<uintptr_t>(bases[i]) % 16 != 0) return hipErrorInvalidValue;
+    a.base[i] = bases[i];
+  }
+  for (int i = 0; i < n_moves; ++i) {
+    if (src[i] < 0 || dst[i] < 0) return hipErrorInvalidValue;
+    a.src[i] = src[i];
+    a.dst[i] = dst[i];
+  }
+  const unsigned tiles = (unsigned)((block_bytes + kCompactTile - 1) / kCompactTile);
+  const size_t grid = (size_t)tiles * (size_t)n_moves * (size_t)n_regions;
+  if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+  if (variant == 1)
+    compact_blocks_reg_kernel<<<dim3((unsigned)grid), dim3(kCompactThreads), 0, stream>>>(a, (unsigned)n_moves, tiles,
+                                                                                         (unsigned)block_bytes);
+  else
+    compact_blocks_lds_kernel<<<dim3((unsigned)grid), dim3(kCompactThreads), 0, stream>>>(a, (unsigned)n_moves, tiles,
+                                                                                         (unsigned)block_bytes);
+  return hipGetLastError();
+}
+
+} // namespace kvc

@@ -1,0 +1,678 @@
+// kv_allocator.cpp — see kv_allocator.hpp.
+#include "kv_allocator.hpp"
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cassert>
+
+#include "kernels.hpp"
+
+namespace kvc {
+
+// ------------------------------------------------------------------ globals
+Options &options() {
+  static Options o;
+  return o;
+}
+Stats &stats() {
+  static Stats s;
+  return s;
+}
+void Stats::reset() {
+  pages_mapped = pages_unmapped = 0;
+  map_calls = unmap_calls = map_ns = unmap_ns = 0;
+  fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
+  vmm.created = vmm.released = vmm.reused = 0;
+  std::lock_guard<std::mutex> g(mu);
+  fill_ms = compact_ms = 0;
+}
+
+namespace {
+std::mutex g_mu; // guards the registry below
+std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> g_allocators;
+std::unordered_map<int, std::unique_ptr<GpuContext>> g_contexts;
+DeviceSpec g_device;
+bool g_contiguous = false;
+bool g_initialized = false;
+size_t g_page_size = kBasePage;
+std::atomic<size_t> g_vaddr_offset{0}; // running offset behind kStartAddr (reference: ftensor.cpp:17)
+std::atomic<size_t> g_override_free{0}, g_override_total{0};
+
+int resolve_dev_index(const DeviceSpec &d) {
+  if (d.index >= 0) return d.index;
+  int cur = 0;
+  HIP_CHECK(hipGetDevice(&cur));
+  return cur;
+}
+
+GpuContext *context_for(int dev) {
+  auto it = g_contexts.find(dev);
+  if (it == g_contexts.end()) it = g_contexts.emplace(dev, std::make_unique<GpuContext>(dev)).first;
+  return it->second.get();
+}
+} // namespace
+
+// ------------------------------------------------------------------ GpuContext
+GpuContext::GpuContext(int dev) : dev_(dev) {
+  HIP_CHECK(hipSetDevice(dev_));
+  int supports_vmm = 0;
+  HIP_CHECK(hipDeviceGetAttribute(&supports_vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev_));
+  if (!supports_vmm)
+    throw InvalidError("VMM is not supported on HIP device " + std::to_string(dev_) +
+                       ". kvcached requires GPU VMM support.");
+  auto prop = make_alloc_prop(dev_, false);
+  size_t gran = 0;
+  HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  if (gran == 0 || g_page_size % gran != 0)
+    throw InvalidError("Invalid page size: " + std::to_string(g_page_size) + " must be a multiple of HIP granularity " +
+                       std::to_string(gran));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+}
+
+GpuContext::~GpuContext() {
+  (void)hipSetDevice(dev_);
+  for (auto &t : inflight_) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  for (auto &e : free_events_) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  pools_[0].clear();
+  pools_[1].clear();
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void GpuContext::bind() const { HIP_CHECK(hipSetDevice(dev_)); }
+
+PhysPool *GpuContext::pool(size_t granule, bool exportable) {
+  std::lock_guard<std::mutex> g(mu_);
+  auto &m = pools_[exportable ? 1 : 0];
+  auto it = m.find(granule);
+  if (it == m.end()) it = m.emplace(granule, std::make_unique<PhysPool>(dev_, granule, exportable, &stats().vmm)).first;
+  it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  return it->second.get();
+}
+
+void GpuContext::drain_pools() {
+  std::vector<PhysPool *> ps;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto &m : pools_)
+      for (auto &kv : m) ps.push_back(kv.second.get());
+  }
+  for (auto *p : ps) p->drain(0);
+}
+
+void GpuContext::begin_timed(hipStream_t s, int kind) {
+  if (!options().profile.load()) return;
+  std::lock_guard<std::mutex> g(mu_);
+  Timed t{nullptr, nullptr, kind};
+  if (!free_events_.empty()) {
+    t.a = free_events_.back().first;
+    t.b = free_events_.back().second;
+    free_events_.pop_back();
+  } else {
+    HIP_CHECK(hipEventCreate(&t.a));
+    HIP_CHECK(hipEventCreate(&t.b));
+  }
+  HIP_CHECK(hipEventRecord(t.a, s));
+  inflight_.push_back(t);
+}
+void GpuContext::end_timed(hipStream_t s) {
+  if (!options().profile.load()) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (!inflight_.empty()) HIP_CHECK(hipEventRecord(inflight_.back().b, s));
+}
+void GpuContext::harvest() {
+  std::lock_guard<std::mutex> g(mu_);
+  if (inflight_.empty()) return;
+  double fill = 0, comp = 0;
+  for (auto &t : inflight_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) (t.kind == 0 ? fill : comp) += ms;
+    free_events_.emplace_back(t.a, t.b);
+  }
+  inflight_.clear();
+  std::lock_guard<std::mutex> g2(stats().mu);
+  stats().fill_ms += fill;
+  stats().compact_ms += comp;
+}
+
+void GpuContext::zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s) {
+  if (!s) s = stream_;
+  const int variant = (int)options().fill_variant.load();
+  for (size_t i = 0; i < n; i += kMaxPtrsPerLaunch) {
+    int k = (int)std::min<size_t>(kMaxPtrsPerLaunch, n - i);
+    begin_timed(s, 0);
+    HIP_CHECK(launch_zero_fill_pages(pages + i, k, page_bytes, s, variant));
+    end_timed(s);
+    stats().fill_launches++;
+    stats().fill_bytes += (int64_t)k * (int64_t)page_bytes;
+  }
+}
+
+void GpuContext::compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
+                         size_t block_bytes, hipStream_t s) {
+  if (!s) s = stream_;
+  const int variant = (int)options().compact_variant.load();
+  for (size_t r = 0; r < n_regions; r += kMaxRegionsPerLaunch) {
+    int nr = (int)std::min<size_t>(kMaxRegionsPerLaunch, n_regions - r);
+    for (size_t m = 0; m < n_moves; m += kMaxMovesPerLaunch) {
+      int nm = (int)std::min<size_t>(kMaxMovesPerLaunch, n_moves - m);
+      begin_timed(s, 1);
+      HIP_CHECK(launch_compact_blocks(bases + r, nr, src + m, dst + m, nm, block_bytes, s, variant));
+      end_timed(s);
+      stats().compact_launches++;
+      stats().compact_bytes += 2ll * nr * nm * (int64_t)block_bytes;
+    }
+  }
+}
+
+void GpuContext::sync(hipStream_t s) {
+  if (!s) s = stream_;
+  HIP_CHECK(hipStreamSynchronize(s));
+  harvest();
+}
+
+// ------------------------------------------------------------------ registry
+void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contiguous_layout) {
+  std::lock_guard<std::mutex> g(g_mu);
+  if (!g_allocators.empty()) {
+    KVC_LOG(LOG_ERROR, "KvAllocator has been initialized. Re-initializing...");
+    g_allocators.clear();
+  }
+  if (page_size > 0) {
+    if (page_size % kBasePage != 0) // reference aborts here (allocator.cpp:84-90); we report it
+      throw InvalidError("Invalid page size: " + std::to_string(page_size) +
+                         ", must be a multiple of 2MB (2097152 bytes)");
+    g_page_size = page_size;
+  }
+  // environment knobs, read once per init
+  options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", true) ? 1 : 0;
+  options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
+  options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 1024) << 20;
+  g_device = parse_device(dev_str);
+  g_contiguous = contiguous_layout;
+  if (g_device.is_gpu) {
+    HIP_CHECK(hipInit(0));
+    g_device.index = resolve_dev_index(g_device);
+    context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
+  }
+  g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout);
+  g_initialized = true;
+}
+
+void KvAllocator::shutdown() {
+  std::lock_guard<std::mutex> g(g_mu);
+  g_allocators.clear();
+  for (auto &kv : g_contexts) kv.second->drain_pools();
+  g_contexts.clear();
+  g_initialized = false;
+}
+
+KvAllocator *KvAllocator::global(int64_t group_id) {
+  std::lock_guard<std::mutex> g(g_mu);
+  auto it = g_allocators.find(group_id);
+  if (it != g_allocators.end()) return it->second.get();
+  if (g_allocators.empty()) throw InvalidError("KvAllocator::init() must be called first (init_kvcached)");
+  // lazily created for an unseen group, with the device/layout of init() (allocator.cpp:101-114)
+  auto &slot = g_allocators[group_id];
+  slot = std::make_unique<KvAllocator>(g_device, g_contiguous);
+  return slot.get();
+}
+
+bool KvAllocator::initialized() {
+  std::lock_guard<std::mutex> g(g_mu);
+  return g_initialized;
+}
+DeviceSpec KvAllocator::device() { return g_device; }
+size_t KvAllocator::page_size() { return g_page_size; }
+GpuContext *KvAllocator::gpu() {
+  std::lock_guard<std::mutex> g(g_mu);
+  if (!g_initialized || !g_device.is_gpu) return nullptr;
+  return context_for(g_device.index);
+}
+
+void mem_get_info(size_t *free_b, size_t *total_b) {
+  size_t of = g_override_free.load(), ot = g_override_total.load();
+  if (ot != 0) {
+    *free_b = of;
+    *total_b = ot;
+    return;
+  }
+  GpuContext *ctx = KvAllocator::gpu();
+  if (!ctx) throw NoGpuError("hipMemGetInfo needs a GPU device (init_kvcached with \"cuda:N\"), or a mem-info override");
+  ctx->bind();
+  HIP_CHECK(hipMemGetInfo(free_b, total_b));
+}
+void set_mem_info_override(size_t free_b, size_t total_b) {
+  g_override_free = free_b;
+  g_override_total = total_b;
+}
+void device_synchronize() {
+  GpuContext *ctx = KvAllocator::gpu();
+  if (!ctx) return;
+  ctx->bind();
+  HIP_CHECK(hipDeviceSynchronize());
+}
+
+// ------------------------------------------------------------------ KvAllocator
+KvAllocator::KvAllocator(DeviceSpec dev, bool contiguous_layout) : dev_(dev), contiguous_(contiguous_layout) {
+  exportable_ = env_bool("KVCACHED_EXPORTABLE_HANDLES", false);
+}
+
+KvAllocator::~KvAllocator() {
+  std::lock_guard<std::mutex> g(mu_);
+  for (auto &r : layers_) destroy_region(*r);
+  layers_.clear();
+  if (have_zero_) {
+    (void)hipMemRelease(zero_handle_);
+    have_zero_ = false;
+  }
+}
+
+std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size_t size, size_t page_size) {
+  if (size % kBasePage != 0) throw InvalidError("alloc size not aligned.");
+  auto r = std::make_unique<KvRegion>();
+  r->name = name;
+  r->size = size;
+  r->page_size = page_size;
+  r->on_gpu = dev_.is_gpu;
+  if (size % page_size != 0) throw InvalidError("region size is not a multiple of its page size");
+  size_t off = g_vaddr_offset.fetch_add(size);
+  void *hint = reinterpret_cast<void *>(kStartAddr + off);
+  if (dev_.is_gpu) {
+    r->base = static_cast<char *>(vmm_reserve(size, kBasePage, hint));
+  } else {
+    void *p = mmap(hint, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) throw InvalidError("mmap failed.");
+    r->base = static_cast<char *>(p);
+  }
+  r->handle.assign(r->num_slots(), phys_handle_t{});
+  r->mapped.assign(r->num_slots(), 0);
+  return r;
+}
+
+// reference: FTensor::init_with_zero_ (ftensor.cpp:160-176) — one shared physical page aliased at every slot,
+// but with ONE ranged hipMemSetAccess instead of one per slot.
+void KvAllocator::backfill_all(KvRegion &r) {
+  auto acc = make_rw_access(gpu()->dev());
+  for (size_t i = 0; i < r.num_slots(); ++i)
+    HIP_CHECK(hipMemMap(r.base + i * r.page_size, r.page_size, 0, zero_handle_, 0));
+  HIP_CHECK(hipMemSetAccess(r.base, r.size, &acc, 1));
+  r.backfilled = true;
+}
+
+void KvAllocator::destroy_region(KvRegion &r) {
+  if (!r.base) return;
+  if (!r.on_gpu) {
+    munmap(r.base, r.size);
+    r.base = nullptr;
+    return;
+  }
+  GpuContext *ctx = gpu();
+  if (ctx) (void)hipSetDevice(ctx->dev());
+  // Tolerate stale mappings during teardown: log, do not throw (ftensor.cpp:78-98).
+  bool whole = false;
+  if (r.backfilled) {
+    hipError_t st = hipMemUnmap(r.base, r.size);
+    whole = st == hipSuccess;
+    if (!whole) KVC_LOG(LOG_ERROR, "hipMemUnmap of whole region %s failed: %s", r.name.c_str(), hipGetErrorString(st));
+  }
+  for (size_t i = 0; i < r.num_slots(); ++i) {
+    if (!r.mapped[i]) continue;
+    if (!whole) {
+      hipError_t st = hipMemUnmap(r.base + i * r.page_size, r.page_size);
+      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemUnmap during cleanup failed: %s", hipGetErrorString(st));
+    }
+    hipError_t st = hipMemRelease(r.handle[i]);
+    if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease during cleanup failed: %s", hipGetErrorString(st));
+    stats().vmm.released++;
+    r.mapped[i] = 0;
+  }
+  hipError_t st = hipMemAddressFree(r.base, r.size);
+  if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemAddressFree during cleanup failed: %s", hipGetErrorString(st));
+  (void)hipGetLastError();
+  r.base = nullptr;
+}
+
+std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size, size_t dtype_size,
+                                                                    const std::string &dev_str, int64_t num_layers,
+                                                                    int64_t num_kv_buffers, bool unified_pool) {
+  if (dtype_size != 1 && dtype_size != 2 && dtype_size != 4 && dtype_size != 8)
+    throw std::runtime_error("Unsupported dtype size: " + std::to_string(dtype_size));
+  if (num_layers <= 0 || num_kv_buffers <= 0) throw InvalidError("num_layers and num_kv_buffers must be positive");
+  (void)dev_str; // the reference only asserts it equals the init device (allocator.cpp:298-301)
+  std::lock_guard<std::mutex> g(mu_);
+  if (num_layers_ != 0 && num_layers_ != num_layers)
+    throw InvalidError("create_kv_tensors called again with a different num_layers");
+  const size_t ps = g_page_size;
+  size_t aligned = size;
+  if (size % ps != 0) {
+    aligned = ((size + ps - 1) / ps) * ps;
+    KVC_LOG(LOG_WARNING, "Size %zu is not aligned to page size %zu, aligning to %zu", size, ps, aligned);
+  }
+  GpuContext *ctx = dev_.is_gpu ? gpu() : nullptr;
+  if (ctx) ctx->bind();
+  const bool backfill = dev_.is_gpu && options().zero_backfill.load();
+  const size_t region_page = contiguous_ ? ps * (size_t)num_layers * (size_t)num_kv_buffers : ps;
+
+  if (backfill && (!have_zero_ || zero_bytes_ != region_page)) {
+    if (have_zero_) (void)hipMemRelease(zero_handle_);
+    auto prop = make_alloc_prop(ctx->dev(), false);
+    HIP_CHECK(hipMemCreate(&zero_handle_, region_page, &prop, 0));
+    zero_bytes_ = region_page;
+    have_zero_ = true;
+  }
+
+  std::vector<TensorDesc> out;
+  if (contiguous_) {
+    // one region for all layers; slot = compound page (page x layers x kv buffers), allocator.cpp:139-147
+    for (auto &r : layers_) destroy_region(*r);
+    layers_.clear();
+    auto r = make_region("kv_contiguous", aligned * (size_t)num_layers, region_page);
+    if (backfill) backfill_all(*r);
+    out.push_back({r->base, r->size});
+    layers_.push_back(std::move(r));
+  } else {
+    if (!layers_.empty() && (layers_.size() != (size_t)num_layers || layers_[0]->size != aligned))
+      throw InvalidError("create_kv_tensors called again with a different size");
+    if (layers_.empty()) {
+      if (num_kv_buffers == 2 && !unified_pool && aligned % (2 * ps) != 0)
+        throw InvalidError("Invalid tensor size: " + std::to_string(aligned) + ", must be a multiple of 2 * page size " +
+                           std::to_string(2 * ps));
+      for (int64_t i = 0; i < num_layers; ++i) {
+        auto r = make_region("kv_" + std::to_string(i), aligned, ps);
+        if (backfill) backfill_all(*r);
+        layers_.push_back(std::move(r));
+      }
+    }
+    for (auto &r : layers_) out.push_back({r->base, r->size});
+  }
+  if (backfill) { // make the shared page really zero, through its first alias
+    void *p = layers_[0]->base;
+    ctx->zero_fill(&p, 1, region_page, nullptr);
+    ctx->sync(nullptr);
+  }
+  num_layers_ = num_layers;
+  num_kv_buffers_ = num_kv_buffers;
+  unified_pool_ = unified_pool;
+  tensor_bytes_per_layer_ = aligned;
+  return out;
+}
+
+bool KvAllocator::kv_tensors_created() {
+  std::lock_guard<std::mutex> g(mu_);
+  return num_layers_ > 0;
+}
+
+std::vector<void *> KvAllocator::region_bases() {
+  std::lock_guard<std::mutex> g(mu_);
+  std::vector<void *> b;
+  for (auto &r : layers_) {
+    b.push_back(r->base);
+    if (!contiguous_ && !unified_pool_ && num_kv_buffers_ == 2) b.push_back(r->base + r->size / 2);
+  }
+  return b;
+}
+
+// Offsets -> (region, slot) in the reference's order: layer-major, then offset, K before V
+// (allocator.cpp:168-207). Contiguous: one compound slot per offset. Unified pool: one slot per layer.
+std::vector<KvAllocator::Slot> KvAllocator::slots_for(const offset_t *offsets, size_t n) {
+  std::vector<Slot> s;
+  auto add = [&](KvRegion *r, offset_t off) {
+    if (off < 0 || (size_t)off % r->page_size != 0 || (size_t)off >= r->size)
+      throw InvalidError("offset " + std::to_string(off) + " is not a valid page offset of " + r->name);
+    s.push_back({r, (size_t)off / r->page_size});
+  };
+  if (contiguous_) {
+    for (size_t i = 0; i < n; ++i) add(layers_[0].get(), offsets[i]);
+  } else if (unified_pool_ || num_kv_buffers_ == 1) {
+    // One slot per layer per offset. NB for a single KV buffer (MLA) the reference's per-layer branch
+    // still maps `offset + size/2` as well (allocator.cpp:189-206), i.e. two pages where its own
+    // accounting (page_allocator.cpp:688-695) counts one, and out of range for the upper half of the
+    // page ids; we back exactly what is accounted (DESIGN.md "reference quirks").
+    s.reserve(layers_.size() * n);
+    for (auto &r : layers_)
+      for (size_t i = 0; i < n; ++i) add(r.get(), offsets[i]);
+  } else {
+    s.reserve(layers_.size() * n * 2);
+    for (auto &r : layers_) {
+      const offset_t v_base = (offset_t)(r->size / 2); // get_v_base_offset, allocator.cpp:46-52
+      for (size_t i = 0; i < n; ++i) {
+        add(r.get(), offsets[i]);
+        add(r.get(), offsets[i] + v_base);
+      }
+    }
+  }
+  return s;
+}
+
+bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
+  const int64_t t0 = now_ns();
+  std::lock_guard<std::mutex> g(mu_);
+  if (num_layers_ == 0) {
+    KVC_LOG(LOG_ERROR, "try to map to KV tensors when KV tensors are not created");
+    return false;
+  }
+  map_slots(slots_for(offsets, n), nullptr);
+  stats().map_calls++;
+  stats().map_ns += now_ns() - t0;
+  return true;
+}
+
+bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
+  const int64_t t0 = now_ns();
+  std::lock_guard<std::mutex> g(mu_);
+  if (num_layers_ == 0) {
+    KVC_LOG(LOG_ERROR, "try to unmap from KV tensors when KV tensors are not created");
+    return false;
+  }
+  unmap_slots(slots_for(offsets, n));
+  stats().unmap_calls++;
+  stats().unmap_ns += now_ns() - t0;
+  return true;
+}
+
+// The hot loop. Per slot: [unmap the zero alias] -> pooled handle -> hipMemMap; per contiguous run: one
+// hipMemSetAccess; per <=256 access-enabled pages: one zero_fill_pages launch that runs on the GPU while
+// the host keeps issuing driver calls for the next slots; one stream sync at the end.
+void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported) {
+  if (slots.empty()) return;
+  if (!dev_.is_gpu) { // reference CPUPage::map is a no-op (page.cpp:34-37); keep the double-map diagnostics
+    for (auto &s : slots) {
+      if (s.region->mapped[s.index]) {
+        KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", s.index);
+        continue;
+      }
+      s.region->mapped[s.index] = 1;
+      stats().pages_mapped++;
+    }
+    return;
+  }
+  GpuContext *ctx = gpu();
+  ctx->bind();
+  const size_t ps = slots[0].region->page_size;
+  PhysPool *pool = ctx->pool(ps, exportable_);
+  const auto acc = make_rw_access(ctx->dev());
+  const bool fill = options().zero_fill.load() && !imported;
+  constexpr size_t kMaxRunBytes = 1ull << 30;
+
+  std::vector<Slot> done;
+  done.reserve(slots.size());
+  std::vector<void *> pending, run_pages;
+  char *run_start = nullptr;
+  size_t run_len = 0;
+  bool launched = false;
+  size_t next_import = 0;
+
+  auto launch_pending = [&](bool all) {
+    size_t i = 0;
+    while (pending.size() - i >= (size_t)kMaxPtrsPerLaunch || (all && i < pending.size())) {
+      size_t k = std::min<size_t>(kMaxPtrsPerLaunch, pending.size() - i);
+      ctx->zero_fill(pending.data() + i, k, ps, nullptr);
+      launched = true;
+      i += k;
+    }
+    pending.erase(pending.begin(), pending.begin() + i);
+  };
+  auto flush_run = [&]() {
+    if (!run_len) return;
+    HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    if (fill) {
+      pending.insert(pending.end(), run_pages.begin(), run_pages.end());
+      launch_pending(false);
+    }
+    run_pages.clear();
+    run_len = 0;
+  };
+
+  try {
+    for (auto &s : slots) {
+      KvRegion &r = *s.region;
+      if (r.mapped[s.index]) { // reference: log + skip, the batch still succeeds (ftensor.cpp:104-107)
+        KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", s.index);
+        if (imported) ++next_import;
+        continue;
+      }
+      char *va = r.base + s.index * ps;
+      if (r.backfilled) HIP_CHECK(hipMemUnmap(va, ps));
+      bool recycled = false;
+      phys_handle_t h = imported ? (*imported)[next_import++] : pool->acquire(&recycled);
+      hipError_t st = hipMemMap(va, ps, 0, h, 0);
+      if (st != hipSuccess) {
+        if (!imported) pool->release(h);
+        if (r.backfilled && hipMemMap(va, ps, 0, zero_handle_, 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
+        HIP_CHECK(st);
+      }
+      r.handle[s.index] = h;
+      r.mapped[s.index] = imported ? 2 : 1;
+      done.push_back(s);
+      if (!(run_len && va == run_start + run_len && run_len < kMaxRunBytes)) {
+        flush_run();
+        run_start = va;
+      }
+      run_len += ps;
+      run_pages.push_back(va);
+    }
+    flush_run();
+    if (fill) launch_pending(true);
+    if (launched) ctx->sync(nullptr);
+  } catch (...) {
+    // leave the regions as they were before this call; PageAllocator rolls the page ids back
+    if (launched) (void)hipStreamSynchronize(ctx->stream());
+    for (auto it = done.rbegin(); it != done.rend(); ++it) {
+      KvRegion &r = *it->region;
+      char *va = r.base + it->index * ps;
+      (void)hipMemUnmap(va, ps);
+      if (r.mapped[it->index] == 1)
+        pool->release(r.handle[it->index]);
+      else
+        (void)hipMemRelease(r.handle[it->index]);
+      r.mapped[it->index] = 0;
+      if (r.backfilled && hipMemMap(va, ps, 0, zero_handle_, 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
+    }
+    (void)hipGetLastError();
+    throw;
+  }
+  stats().pages_mapped += (int64_t)done.size();
+}
+
+void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
+  if (slots.empty()) return;
+  if (!dev_.is_gpu) {
+    for (auto &s : slots) {
+      if (!s.region->mapped[s.index]) {
+        KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", s.index);
+        continue;
+      }
+      s.region->mapped[s.index] = 0;
+      stats().pages_unmapped++;
+    }
+    return;
+  }
+  GpuContext *ctx = gpu();
+  ctx->bind();
+  const size_t ps = slots[0].region->page_size;
+  PhysPool *pool = ctx->pool(ps, exportable_);
+  const auto acc = make_rw_access(ctx->dev());
+  char *run_start = nullptr;
+  size_t run_len = 0;
+  auto flush_run = [&]() {
+    if (!run_len) return;
+    HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    run_len = 0;
+  };
+  int64_t n_done = 0;
+  for (auto &s : slots) {
+    KvRegion &r = *s.region;
+    if (!r.mapped[s.index]) { // reference: log + skip (ftensor.cpp:124-127)
+      KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", s.index);
+      continue;
+    }
+    char *va = r.base + s.index * ps;
+    HIP_CHECK(hipMemUnmap(va, ps));
+    if (r.mapped[s.index] == 1) {
+      pool->release(r.handle[s.index]);
+    } else {
+      hipError_t st = hipMemRelease(r.handle[s.index]);
+      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
+    }
+    r.mapped[s.index] = 0;
+    ++n_done;
+    if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
+      HIP_CHECK(hipMemMap(va, ps, 0, zero_handle_, 0));
+      if (!(run_len && va == run_start + run_len)) {
+        flush_run();
+        run_start = va;
+      }
+      run_len += ps;
+    }
+  }
+  flush_run();
+  stats().pages_unmapped += n_done;
+}
+
+// ------------------------------------------------------------------ TP shared pool
+int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!dev_.is_gpu) throw NoGpuError("export_mapped_slots needs a GPU device");
+  if (!exportable_) throw InvalidError("handles are not exportable: set KVCACHED_EXPORTABLE_HANDLES=1 before init");
+  auto slots = slots_for(offsets, n);
+  if ((int64_t)slots.size() > cap) return (int)slots.size();
+  gpu()->bind();
+  int k = 0;
+  for (auto &s : slots) {
+    if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
+    int fd = -1;
+    HIP_CHECK(hipMemExportToShareableHandle(&fd, s.region->handle[s.index], hipMemHandleTypePosixFileDescriptor, 0));
+    out_fds[k++] = fd;
+  }
+  return k;
+}
+
+bool KvAllocator::map_imported_slots(const offset_t *offsets, size_t n, const int *fds, size_t n_fds) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!dev_.is_gpu) throw NoGpuError("map_imported_slots needs a GPU device");
+  if (num_layers_ == 0) return false;
+  auto slots = slots_for(offsets, n);
+  if (slots.size() != n_fds) throw InvalidError("fd count does not match the slot count of the offsets");
+  gpu()->bind();
+  std::vector<phys_handle_t> hs(n_fds);
+  size_t i = 0;
+  try {
+    for (; i < n_fds; ++i)
+      HIP_CHECK(hipMemImportFromShareableHandle(&hs[i], (void *)(uintptr_t)fds[i], hipMemHandleTypePosixFileDescriptor));
+  } catch (...) {
+    for (size_t j = 0; j < i; ++j) (void)hipMemRelease(hs[j]);
+    throw;
+  }
+  map_slots(slots, &hs);
+  return true;
+}
+
+} // namespace kvc

@@ -1,0 +1,151 @@
+// kv_allocator.hpp — VA regions + the batched map/unmap hot path.
+//
+// Counterpart of the reference's FTensor (csrc/ftensor.cpp), GPUPage/CPUPage (csrc/page.cpp)
+// and FTensorAllocator (csrc/allocator.cpp), re-designed around what the MI355X driver
+// charges for (hip_vmm.hpp): slots are tracked in flat vectors instead of one heap object
+// + hash-map node per page, a whole map_to_kv_tensors() call is one batch (pooled handles,
+// ranged hipMemSetAccess, one zero_fill_pages launch per <=256 pages overlapped with the
+// remaining driver calls, a single stream sync at the end), and failures roll the batch back
+// instead of aborting the process.
+#pragma once
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.hpp"
+#include "hip_vmm.hpp"
+
+namespace kvc {
+
+struct Options {
+  std::atomic<int64_t> zero_backfill{1};
+  std::atomic<int64_t> zero_fill{1};
+  std::atomic<int64_t> pool_bytes{1024ll << 20};
+  std::atomic<int64_t> profile{0};
+  std::atomic<int64_t> fill_variant{0};
+  std::atomic<int64_t> compact_variant{0};
+};
+Options &options();
+
+struct Stats {
+  std::atomic<int64_t> pages_mapped{0}, pages_unmapped{0};
+  std::atomic<int64_t> map_calls{0}, unmap_calls{0}, map_ns{0}, unmap_ns{0};
+  std::atomic<int64_t> fill_launches{0}, fill_bytes{0};
+  std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
+  std::mutex mu;
+  double fill_ms = 0, compact_ms = 0;
+  VmmCounters vmm;
+  void reset();
+};
+Stats &stats();
+
+// Per-device state: stream for our kernels, event pool for per-launch timing, handle pools.
+class GpuContext {
+public:
+  explicit GpuContext(int dev);
+  ~GpuContext();
+  int dev() const { return dev_; }
+  void bind() const; // hipSetDevice for the calling thread (HIP's current device is per thread)
+  hipStream_t stream() const { return stream_; }
+  PhysPool *pool(size_t granule, bool exportable);
+  void drain_pools();
+
+  // kernel launches on `s` (NULL = own stream), timed with events when profiling is on
+  void zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s);
+  void compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
+               size_t block_bytes, hipStream_t s);
+  void sync(hipStream_t s); // hipStreamSynchronize + harvest event timings
+
+private:
+  struct Timed {
+    hipEvent_t a, b;
+    int kind; // 0 fill, 1 compact
+  };
+  void begin_timed(hipStream_t s, int kind);
+  void end_timed(hipStream_t s);
+  void harvest();
+  int dev_;
+  hipStream_t stream_ = nullptr;
+  std::mutex mu_;
+  std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];
+  std::vector<Timed> inflight_;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
+};
+
+// One contiguous VA reservation cut into fixed-size slots (the reference's FTensor).
+struct KvRegion {
+  std::string name;
+  char *base = nullptr;
+  size_t size = 0;
+  size_t page_size = 0;
+  bool on_gpu = false;
+  bool backfilled = false;             // every unbacked slot currently aliases the zero page
+  std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
+  std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page
+  size_t num_slots() const { return size / page_size; }
+};
+
+class KvAllocator {
+public:
+  // process-wide registry keyed by group id (reference: FTensorAllocator multiton, allocator.cpp:18-22,72-119)
+  static void init(const std::string &dev_str, size_t page_size, bool contiguous_layout);
+  static void shutdown();
+  static KvAllocator *global(int64_t group_id);
+  static bool initialized();
+  static DeviceSpec device();
+  static GpuContext *gpu(); // context of the init device (nullptr on "cpu")
+  static size_t page_size();
+
+  KvAllocator(DeviceSpec dev, bool contiguous_layout);
+  ~KvAllocator();
+
+  struct TensorDesc {
+    void *ptr;
+    size_t nbytes;
+  };
+  std::vector<TensorDesc> create_kv_tensors(size_t size, size_t dtype_size, const std::string &dev_str,
+                                            int64_t num_layers, int64_t num_kv_buffers, bool unified_pool);
+  bool kv_tensors_created();
+  bool map_to_kv_tensors(const offset_t *offsets, size_t n);
+  bool unmap_from_kv_tensors(const offset_t *offsets, size_t n);
+  std::vector<void *> region_bases(); // layer-major, K then V (compact_blocks' region table)
+
+  // TP shared pool
+  int export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap);
+  bool map_imported_slots(const offset_t *offsets, size_t n, const int *fds, size_t n_fds);
+
+private:
+  struct Slot {
+    KvRegion *region;
+    size_t index;
+  };
+  std::vector<Slot> slots_for(const offset_t *offsets, size_t n);
+  std::unique_ptr<KvRegion> make_region(const std::string &name, size_t size, size_t page_size);
+  void destroy_region(KvRegion &r);
+  void backfill_all(KvRegion &r);
+  void map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported);
+  void unmap_slots(const std::vector<Slot> &slots);
+
+  DeviceSpec dev_;
+  bool contiguous_;
+  bool unified_pool_ = false;
+  bool exportable_ = false;
+  int64_t num_layers_ = 0;
+  int64_t num_kv_buffers_ = 2;
+  size_t tensor_bytes_per_layer_ = 0;
+  std::mutex mu_;
+  std::vector<std::unique_ptr<KvRegion>> layers_; // per-layer regions, or ONE region in contiguous layout
+  phys_handle_t zero_handle_{};
+  size_t zero_bytes_ = 0;
+  bool have_zero_ = false;
+};
+
+// hipMemGetInfo of the init device, or the test override.
+void mem_get_info(size_t *free_b, size_t *total_b);
+void set_mem_info_override(size_t free_b, size_t total_b);
+void device_synchronize();
+
+} // namespace kvc

@@ -1,0 +1,299 @@
+"""Shared test infrastructure: a tiny trace language for KVCacheManager / PageAllocator
+behaviour, a replay engine, and adapters for (a) the CPU oracle (oracle/libkvc_oracle.so)
+and (b) the product (kvcached_amd). oracle/gen_golden.py reuses the replay engine with a
+third adapter that drives the REAL reference, so that goldens, oracle and product are all
+compared through exactly the same code path.
+
+Trace ops (JSON arrays, first element is the opcode):
+  ["a", req, n]            blocks[req] = alloc(n)                (None allowed)
+  ["f", req]               free(blocks[req]); forget req
+  ["fp", req, lo, hi]      free(blocks[req][lo:hi]); keep the rest under req
+  ["rs", n]                try_to_reserve(n)
+  ["fr"]                   free_reserved()
+  ["rz", mem_bytes]        resize(mem_bytes)
+  ["tr"]                   trim()
+  ["ph", pages]            set what get_avail_physical_pages() reports
+  ["pre"]                  run one synchronous prealloc pass (oracle/product-cpu only)
+Each op yields a record {"r": result, "s": snapshot, "e": events}.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import struct
+from typing import Any, Dict, List, Optional, Sequence
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+ORACLE_SO = os.path.join(REPO, "oracle", "libkvc_oracle.so")
+
+MiB = 1 << 20
+PAGE = 2 * MiB
+
+
+def h64(ints: Sequence[int]) -> str:
+    """Short stable hash of an int64 list (little-endian bytes, sha256, 16 hex chars)."""
+    b = struct.pack("<%dq" % len(ints), *ints) if len(ints) else b""
+    return hashlib.sha256(b).hexdigest()[:16]
+
+
+def summarise(ints: Optional[Sequence[int]], full: bool) -> Any:
+    if ints is None:
+        return None
+    ints = list(ints)
+    if full:
+        return ints
+    return {"n": len(ints), "h": h64(ints), "head": ints[:4], "tail": ints[-2:]}
+
+
+class Adapter:
+    """Interface every implementation under comparison provides."""
+
+    def alloc(self, n: int) -> Optional[List[int]]: ...
+    def free(self, ids: List[int]) -> None: ...
+    def try_to_reserve(self, n: int) -> bool: ...
+    def free_reserved(self) -> None: ...
+    def resize(self, mem: int) -> bool: ...
+    def trim(self) -> None: ...
+    def set_phys(self, pages: int) -> None: ...
+    def prealloc_step(self) -> int: raise NotImplementedError
+    def available_size(self) -> int: ...
+    def snapshot(self) -> List[int]: ...
+    def drain_events(self) -> List[List[Any]]: ...
+    def close(self) -> None: ...
+
+
+def replay(ad: Adapter, ops: List[List[Any]], full: bool = False) -> List[Dict[str, Any]]:
+    blocks: Dict[int, List[int]] = {}
+    out = []
+    for op in ops:
+        code = op[0]
+        r: Any = None
+        if code == "a":
+            got = ad.alloc(op[2])
+            if got is not None:
+                blocks[op[1]] = list(got)
+            r = summarise(got, full)
+        elif code == "f":
+            ad.free(blocks.pop(op[1], []))
+        elif code == "fp":
+            cur = blocks.get(op[1], [])
+            part = cur[op[2]:op[3]]
+            blocks[op[1]] = cur[:op[2]] + cur[op[3]:]
+            ad.free(part)
+        elif code == "rs":
+            r = bool(ad.try_to_reserve(op[1]))
+        elif code == "fr":
+            ad.free_reserved()
+        elif code == "rz":
+            r = bool(ad.resize(op[1]))
+        elif code == "tr":
+            ad.trim()
+        elif code == "ph":
+            ad.set_phys(op[1])
+        elif code == "pre":
+            r = ad.prealloc_step()
+        else:
+            raise ValueError(f"bad op {op}")
+        ev = ad.drain_events()
+        if not full:
+            ev = [[k, summarise(o, len(o) <= 8)] for k, o in ev]
+        out.append({"r": r, "s": ad.snapshot(), "e": ev})
+    return out
+
+
+def chain_hash(records: List[Dict[str, Any]], every: int = 100) -> Dict[str, Any]:
+    """Running sha256 over the JSON of each record; checkpoints localise a mismatch."""
+    import json
+    h = hashlib.sha256()
+    cps = []
+    for i, rec in enumerate(records):
+        h.update(json.dumps(rec, sort_keys=True, separators=(",", ":")).encode())
+        if (i + 1) % every == 0:
+            cps.append(h.hexdigest()[:16])
+    return {"final": h.hexdigest(), "checkpoints": cps, "every": every, "n": len(records)}
+
+
+# --------------------------------------------------------------------------- oracle adapter
+_I64P = ctypes.POINTER(ctypes.c_int64)
+
+
+def load_oracle() -> ctypes.CDLL:
+    if not os.path.exists(ORACLE_SO):
+        raise RuntimeError(f"{ORACLE_SO} missing: run `make -C oracle oracle` (or __graft_entry__.build())")
+    lib = ctypes.CDLL(ORACLE_SO)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    sig = {
+        "okvc_last_error": (ctypes.c_char_p, []),
+        "okvc_get_block_range": (None, [i64, i64, i64, _I64P, _I64P]),
+        "okvc_get_num_blocks": (i64, [i64, i64]),
+        "okvc_page_new": (vp, [i64, i64]), "okvc_page_delete": (None, [vp]),
+        "okvc_page_init": (None, [vp, i64]), "okvc_page_alloc": (i64, [vp, i64, _I64P]),
+        "okvc_page_free": (None, [vp, i64]), "okvc_page_free_batch": (None, [vp, _I64P, i64]),
+        "okvc_page_empty": (ci, [vp]), "okvc_page_full": (ci, [vp]), "okvc_page_num_free": (i64, [vp]),
+        "okvc_page_free_blocks": (i64, [vp, _I64P, i64]),
+        "okvc_pa_new": (vp, [i64, i64, i64, i64, ci, ci, i64, i64, i64]), "okvc_pa_delete": (None, [vp]),
+        "okvc_pa_alloc_page": (i64, [vp]), "okvc_pa_free_page": (None, [vp, i64]),
+        "okvc_pa_free_pages": (None, [vp, _I64P, i64]), "okvc_pa_resize": (ci, [vp, i64]),
+        "okvc_pa_trim": (None, [vp]), "okvc_pa_reset_free_page_order": (None, [vp]),
+        "okvc_pa_prealloc_step": (i64, [vp]), "okvc_pa_set_prealloc_needed": (None, [vp, ci]),
+        "okvc_pa_set_avail_phys_pages": (None, [vp, i64]), "okvc_pa_set_shm_total": (None, [vp, i64]),
+        "okvc_pa_watcher_tick": (None, [vp]), "okvc_pa_get_resize_target": (i64, [vp]),
+        "okvc_pa_get_page_id": (i64, [vp, i64, i64]), "okvc_pa_stats": (None, [vp, _I64P]),
+        "okvc_pa_list": (i64, [vp, ci, _I64P, i64]),
+        "okvc_pa_group_indices": (i64, [vp, _I64P, i64, i64, _I64P, _I64P, _I64P]),
+        "okvc_pa_drain_log": (i64, [vp, _I64P, i64]),
+        "okvc_mgr_new": (vp, [i64, i64, i64, i64, i64, ci, i64, i64, ci, ci, i64, i64]),
+        "okvc_mgr_delete": (None, [vp]), "okvc_mgr_pa": (vp, [vp]), "okvc_mgr_post_init": (ci, [vp]),
+        "okvc_mgr_alloc": (i64, [vp, i64, _I64P]), "okvc_mgr_free": (ci, [vp, _I64P, i64]),
+        "okvc_mgr_try_to_reserve": (ci, [vp, i64]), "okvc_mgr_free_reserved": (ci, [vp]),
+        "okvc_mgr_resize": (ci, [vp, i64]), "okvc_mgr_trim": (None, [vp]), "okvc_mgr_clear": (ci, [vp]),
+        "okvc_mgr_available_size": (i64, [vp]), "okvc_mgr_reserved_blocks": (i64, [vp, _I64P, i64]),
+        "okvc_mgr_stats": (None, [vp, _I64P]),
+        "okvc_zero_fill_pages": (None, [ctypes.POINTER(vp), i64, i64]),
+        "okvc_compact_blocks": (None, [ctypes.POINTER(vp), i64, _I64P, _I64P, i64, i64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _arr(vals: Sequence[int]):
+    return (ctypes.c_int64 * max(1, len(vals)))(*vals)
+
+
+def _drain_flat(buf, n) -> List[List[Any]]:
+    ev, i = [], 0
+    while i < n:
+        kind, cnt = buf[i], buf[i + 1]
+        ev.append([int(kind), [int(x) for x in buf[i + 2:i + 2 + cnt]]])
+        i += 2 + cnt
+    return ev
+
+
+class OraclePA:
+    """ctypes view of the oracle's PageAllocator (used directly and through OracleAdapter)."""
+
+    def __init__(self, lib, handle, owned=True):
+        self.lib, self.h, self.owned = lib, handle, owned
+
+    @classmethod
+    def create(cls, lib, num_layers, mem, page_size=PAGE, world_size=1, contiguous=False, prealloc=False,
+               num_kv_buffers=2, min_res=5, max_res=10):
+        return cls(lib, lib.okvc_pa_new(num_layers, mem, page_size, world_size, int(contiguous), int(prealloc),
+                                        num_kv_buffers, min_res, max_res))
+
+    def alloc_page(self) -> int:
+        pid = self.lib.okvc_pa_alloc_page(self.h)
+        if pid < 0:
+            raise RuntimeError(self.lib.okvc_last_error().decode())
+        return pid
+
+    def free_page(self, pid): self.lib.okvc_pa_free_page(self.h, pid)
+    def free_pages(self, pids): self.lib.okvc_pa_free_pages(self.h, _arr(pids), len(pids))
+    def resize(self, mem) -> bool: return bool(self.lib.okvc_pa_resize(self.h, mem))
+    def trim(self): self.lib.okvc_pa_trim(self.h)
+    def reset_free_page_order(self): self.lib.okvc_pa_reset_free_page_order(self.h)
+    def prealloc_step(self) -> int: return self.lib.okvc_pa_prealloc_step(self.h)
+    def set_prealloc_needed(self, v=True): self.lib.okvc_pa_set_prealloc_needed(self.h, int(v))
+    def set_phys(self, pages): self.lib.okvc_pa_set_avail_phys_pages(self.h, pages)
+    def get_page_id(self, b, B): return self.lib.okvc_pa_get_page_id(self.h, b, B)
+
+    def stats(self) -> List[int]:
+        o = (ctypes.c_int64 * 7)()
+        self.lib.okvc_pa_stats(self.h, o)
+        return list(o)
+
+    def lst(self, which: int) -> List[int]:
+        n = self.lib.okvc_pa_list(self.h, which, None, 0)
+        buf = (ctypes.c_int64 * max(1, n))()
+        self.lib.okvc_pa_list(self.h, which, buf, n)
+        return list(buf[:n])
+
+    def group_indices_by_page(self, idx: Sequence[int], B: int) -> Dict[int, List[int]]:
+        n = len(idx)
+        keys, counts, vals = _arr([0] * n), _arr([0] * n), _arr([0] * n)
+        k = self.lib.okvc_pa_group_indices(self.h, _arr(idx), n, B, keys, counts, vals)
+        out, w = {}, 0
+        for i in range(k):
+            out[int(keys[i])] = [int(v) for v in vals[w:w + counts[i]]]
+            w += counts[i]
+        return out
+
+    def drain_events(self):
+        n = self.lib.okvc_pa_drain_log(self.h, None, 0)
+        buf = (ctypes.c_int64 * max(1, n))()
+        self.lib.okvc_pa_drain_log(self.h, buf, n)
+        return _drain_flat(buf, n)
+
+    def close(self):
+        if self.owned and self.h:
+            self.lib.okvc_pa_delete(self.h)
+            self.h = None
+
+
+class OracleAdapter(Adapter):
+    def __init__(self, lib, num_blocks, block_size, cell_size, num_layers, world_size=1, reserve_null_block=False,
+                 num_kv_buffers=2, page_size=PAGE, contiguous=False, prealloc=False, min_res=5, max_res=10,
+                 phys_pages=1 << 40):
+        self.lib = lib
+        self.h = lib.okvc_mgr_new(num_blocks, block_size, cell_size, num_layers, world_size, int(reserve_null_block),
+                                  num_kv_buffers, page_size, int(contiguous), int(prealloc), min_res, max_res)
+        self.pa = OraclePA(lib, lib.okvc_mgr_pa(self.h), owned=False)
+        self.pa.set_phys(phys_pages)
+        rc = lib.okvc_mgr_post_init(self.h)
+        if rc != 0:
+            raise RuntimeError("Failed to reserve null block at index 0")
+
+    def alloc(self, n):
+        buf = (ctypes.c_int64 * max(1, n))()
+        k = self.lib.okvc_mgr_alloc(self.h, n, buf)
+        if k == -1:
+            return None
+        if k < 0:
+            raise RuntimeError(self.lib.okvc_last_error().decode())
+        return list(buf[:k])
+
+    def free(self, ids):
+        if self.lib.okvc_mgr_free(self.h, _arr(ids), len(ids)) != 0:
+            raise RuntimeError(self.lib.okvc_last_error().decode())
+
+    def try_to_reserve(self, n): return bool(self.lib.okvc_mgr_try_to_reserve(self.h, n))
+    def free_reserved(self): self.lib.okvc_mgr_free_reserved(self.h)
+
+    def resize(self, mem):
+        rc = self.lib.okvc_mgr_resize(self.h, mem)
+        if rc < 0:
+            raise AssertionError("Reserved blocks must be freed before resizing.")
+        return bool(rc)
+
+    def trim(self): self.lib.okvc_mgr_trim(self.h)
+    def clear(self): self.lib.okvc_mgr_clear(self.h)
+    def set_phys(self, pages): self.pa.set_phys(pages)
+    def prealloc_step(self): return self.pa.prealloc_step()
+    def available_size(self): return self.lib.okvc_mgr_available_size(self.h)
+
+    def reserved_blocks(self):
+        n = self.lib.okvc_mgr_reserved_blocks(self.h, None, 0)
+        buf = (ctypes.c_int64 * max(1, n))()
+        self.lib.okvc_mgr_reserved_blocks(self.h, buf, n)
+        return list(buf[:n])
+
+    def mgr_stats(self):
+        o = (ctypes.c_int64 * 7)()
+        self.lib.okvc_mgr_stats(self.h, o)
+        return list(o)
+
+    def snapshot(self):
+        free, inuse, total, reserved, st, su, sp = self.pa.stats()
+        ms = self.mgr_stats()
+        return [self.available_size(), free, inuse, total, reserved, ms[3], ms[4], st, su, sp]
+
+    def drain_events(self): return self.pa.drain_events()
+
+    def close(self):
+        if self.h:
+            self.lib.okvc_mgr_delete(self.h)
+            self.h = None
