@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""bench.py — GB/s of KV physically backed (map + zero) at 2 MiB granularity on MI355X.
+
+Workload (BASELINE.json configs[1], "bench_vmm"): reserve >= 64 GiB of VA, back it in batches of
+1024 x 2 MiB pages. One STEP = one call of the batched hot path on one batch:
+kvc_map_to_kv_tensors(1024 offsets) = pooled/created physical handles + hipMemMap + ranged
+hipMemSetAccess + the zero_fill_pages kernel, returning after the fill completed. Offsets inside
+a batch are a seed-0 permutation. Unmapping happens after the timed region and is
+reported separately (`unmap_GBps`).
+
+  python bench.py [--gpus N --steps K --warmup W]
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the path shards with no
+data-path collective — every rank backs its own KV shard — and the only exchange is the one the
+reference has too: rank 0's offset vector is broadcast to the TP group (CollectiveFanout: one RCCL
+broadcast + one status all-reduce per step). Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line: metric/value/unit/... + "roofline" (zero_fill_pages, HBM-bound; kernel time
+from HIP events recorded inside the library on the stream the kernel runs on) + "cpu_baseline"
+(the CPU oracle timed on the host cores, rank 0 at N = 1) + extras (p50 batch latency, per-mode
+variants, and — when oracle/_ref exists — the REAL reference's HIP path timed on the same box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MiB, GiB = 1 << 20, 1 << 30
+PAGE = 2 * MiB
+BATCH_PAGES = 1024
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--mode", choices=["compat", "lazy"], default="compat",
+                    help="compat: unbacked VA aliases a zero page like the reference (default); lazy: no backfill")
+    ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def batch_offsets(batch_index: int, seed: int = 0):
+    import numpy as np
+    perm = np.random.default_rng(seed + batch_index).permutation(BATCH_PAGES)
+    base = batch_index * BATCH_PAGES
+    return [int(base + p) * PAGE for p in perm]
+
+
+class Pool:
+    """One region of `window` batches, driven through the C ABI."""
+
+    def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0):
+        self.capi, self.device, self.window = capi, device, window_batches
+        os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
+        if pool_mb is not None:
+            os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
+        else:
+            os.environ.pop("KVCACHED_PHYS_POOL_MB", None)
+        capi.init(device, page, False)
+        self.size = window_batches * BATCH_PAGES * page
+        t0 = time.perf_counter()
+        # one layer, one buffer, unified pool: one 2 MiB slot per offset (the bench_vmm shape)
+        self.tensors = capi.create_kv_tensors(self.size, 1, device, 1, 1, group_id, True)
+        self.reserve_s = time.perf_counter() - t0
+
+    def close(self):
+        self.capi.shutdown()
+
+
+def run_steps(capi, mapper, first_batch: int, n: int):
+    """n timed map+zero steps; returns per-step seconds."""
+    per = []
+    for i in range(n):
+        offs = batch_offsets(first_batch + i)
+        t0 = time.perf_counter()
+        mapper(offs)
+        per.append(time.perf_counter() - t0)
+    return per
+
+
+def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None):
+    window = max(32, steps + warmup)  # >= 64 GiB of VA
+    pool = Pool(capi, device, window, mode, pool_mb)
+    try:
+        if fanout is not None:
+            mapper = lambda offs: fanout.map_to_kv_tensors(offs)     # noqa: E731  rank 0's offsets win
+            unmapper = lambda offs: fanout.unmap_from_kv_tensors(offs)  # noqa: E731
+        else:
+            mapper, unmapper = capi.map_to_kv_tensors, capi.unmap_from_kv_tensors
+        # warm-up: back W batches and give them back, so that code paths are warm and the idle-handle
+        # pool holds what its cap allows (the steady state of an elastic pool)
+        run_steps(capi, mapper, 0, warmup)
+        for b in range(warmup):
+            unmapper(batch_offsets(b))
+        capi.set_option(capi.OPT_PROFILE, 1)
+        capi.reset_stats()
+        if barrier:
+            barrier()
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        per = run_steps(capi, mapper, warmup, steps)
+        if sync:
+            sync()
+        if barrier:
+            barrier()
+        elapsed = time.perf_counter() - t0
+        st = capi.get_stats()
+        capi.set_option(capi.OPT_PROFILE, 0)
+        # give everything back (untimed for the headline, reported on its own)
+        t1 = time.perf_counter()
+        for b in range(warmup, warmup + steps):
+            unmapper(batch_offsets(b))
+        unmap_s = time.perf_counter() - t1
+        return {"elapsed": elapsed, "per_step": per, "stats": st, "unmap_s": unmap_s, "reserve_s": pool.reserve_s,
+                "window_GiB": pool.size / GiB}
+    finally:
+        pool.close()
+
+
+def summarize(res, steps, n_gpus=1):
+    bytes_per_step = BATCH_PAGES * PAGE
+    st = res["stats"]
+    out = {
+        "GBps": n_gpus * steps * bytes_per_step / res["elapsed"] / 1e9,
+        "ms_per_step": res["elapsed"] / steps * 1e3,
+        "p50_map_batch_ms": statistics.median(res["per_step"]) * 1e3,
+        "p90_map_batch_ms": sorted(res["per_step"])[int(0.9 * (len(res["per_step"]) - 1))] * 1e3,
+        "us_per_page": res["elapsed"] / steps / BATCH_PAGES * 1e6,
+        "unmap_GBps": (len(res["per_step"]) + 0) * bytes_per_step / max(res["unmap_s"], 1e-9) / 1e9,
+        "handles_created": st["handles_created"], "handles_reused": st["handles_reused"],
+        "va_reserve_and_backfill_s": res["reserve_s"],
+    }
+    return out
+
+
+def roofline_from(st):
+    launches, ms, nbytes = st["fill_launches"], st["fill_ms"], st["fill_bytes"]
+    if not launches or ms <= 0:
+        return None
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "zero_fill_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get("write_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"kernel": "zero_fill_pages", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "launches": launches, "bytes_per_launch": nbytes // launches,
+            "avg_launch_us": round(ms / launches * 1e3, 2)}
+
+
+def cpu_baseline():
+    """The reference's CPU path restated (oracle/, kind "port"), 1 thread, bounded sample: for each
+    batch the page-id bookkeeping of the reference allocator (PageAllocator state machine ->
+    offsets) and the CPU statement of map+zero on host memory (anonymous mmap like the reference's
+    cpu device, csrc/ftensor.cpp:40-44; CPUPage::map is a no-op, so "zero" = memset)."""
+    import ctypes
+    import mmap
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import kvc_testlib as T
+    lib = T.load_oracle()
+    batches = 6
+    size = batches * BATCH_PAGES * PAGE
+    buf = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    anchor = ctypes.c_char.from_buffer(buf)
+    base = ctypes.addressof(anchor)
+    pa = T.OraclePA.create(lib, 1, size, PAGE, num_kv_buffers=1, max_res=0, min_res=0)
+    t0 = time.perf_counter()
+    for b in range(batches):
+        pids = [pa.alloc_page() for _ in range(BATCH_PAGES)]           # bookkeeping
+        ev = pa.drain_events()
+        offs = [o for _, os_ in ev for o in os_]
+        assert len(offs) == BATCH_PAGES and len(pids) == BATCH_PAGES
+        ptrs = (ctypes.c_void_p * BATCH_PAGES)(*[base + o for o in offs])
+        lib.okvc_zero_fill_pages(ptrs, BATCH_PAGES, PAGE)               # "map" is a no-op on the cpu device
+    dt = time.perf_counter() - t0
+    pa.close()
+    del ptrs, anchor
+    buf.close()
+    return {"value": round(batches * BATCH_PAGES * PAGE / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{batches} batches x {BATCH_PAGES} x 2 MiB: oracle PageAllocator bookkeeping + memset of "
+                      f"first-touched anonymous host memory ({dt:.1f} s)",
+            "host_cores_available": os.cpu_count()}
+
+
+REF_SNIPPET = r"""
+import importlib.machinery, importlib.util, json, sys, time, torch
+so = sys.argv[1]
+loader = importlib.machinery.ExtensionFileLoader("vmm_ops", so)
+spec = importlib.util.spec_from_loader("vmm_ops", loader)
+ref = importlib.util.module_from_spec(spec); loader.exec_module(ref)
+PAGE, N, B = 2 << 20, 1024, int(sys.argv[2])
+import numpy as np
+ref.init_kvcached("cuda:0", PAGE, False)
+t0 = time.perf_counter()
+ref.create_kv_tensors(B * N * PAGE, 1, "cuda:0", 1, 1, 0, True)
+t_create = time.perf_counter() - t0
+per = []
+for b in range(B):
+    offs = [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
+    t0 = time.perf_counter(); assert ref.map_to_kv_tensors(offs); per.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+tu = time.perf_counter()
+for b in range(B):
+    offs = [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
+    assert ref.unmap_from_kv_tensors(offs)
+tu = time.perf_counter() - tu
+per = per[1:] if len(per) > 2 else per
+print(json.dumps({"GBps": N * PAGE / (sum(per) / len(per)) / 1e9, "p50_map_batch_ms": sorted(per)[len(per)//2] * 1e3,
+                  "us_per_page": sum(per) / len(per) / N * 1e6, "unmap_GBps": B * N * PAGE / tu / 1e9,
+                  "va_reserve_and_backfill_s": t_create, "batches": B}))
+ref.shutdown_kvcached()
+"""
+
+
+def reference_on_box():
+    """The REAL reference (oracle/_ref/vmm_ops.so, compiled from its own sources in the build
+    container) running its own HIP path on this GPU: same batch shape, its FTensor::map per page
+    (unmap zero alias + hipMemCreate + hipMemMap + hipMemSetAccess, no zero fill). Context only."""
+    so = os.path.join(REPO, "oracle", "_ref", "vmm_ops.so")
+    if not os.path.exists(so):
+        return None
+    try:
+        out = subprocess.run([sys.executable, "-c", REF_SNIPPET, so, "6"], capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not line:
+            return {"error": (out.stderr or out.stdout)[-300:]}
+        d = json.loads(line[-1])
+        d["what"] = "reference csrc (KVCACHED_USE_HIP) map_to_kv_tensors, 1024 x 2 MiB per call, no zero fill"
+        return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
+    except Exception as e:  # never let the context number break the bench line
+        return {"error": str(e)[:200]}
+
+
+def main():
+    args = parse_args()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_{os.getpid()}")
+    os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    from kvcached_amd import capi
+
+    fanout = barrier = None
+    sync = torch.cuda.synchronize
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        from kvcached_amd.tp_ipc_util import CollectiveFanout
+        fanout = CollectiveFanout(device=device)
+        barrier = dist.barrier
+
+    res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync)
+    elapsed = res["elapsed"]
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        res["elapsed"] = elapsed
+    main_sum = summarize(res, args.steps, world)
+
+    if rank == 0:
+        line = {
+            "metric": "GB/s KV backed (map+zero), 2 MiB pages",
+            "value": round(main_sum["GBps"], 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(main_sum["ms_per_step"], 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "bench_vmm: >=64 GiB VA, 1024 x 2 MiB pages per batch, seed-0 shuffled offsets",
+                       "mode": args.mode, "page_MiB": 2, "batch_pages": BATCH_PAGES,
+                       "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
+                       "fanout": "rccl broadcast + all-reduce(min)" if world > 1 else "local"},
+            "p50_map_batch_ms": round(main_sum["p50_map_batch_ms"], 3),
+            "p90_map_batch_ms": round(main_sum["p90_map_batch_ms"], 3),
+            "us_per_page": round(main_sum["us_per_page"], 3),
+            "unmap_GBps": round(main_sum["unmap_GBps"], 2),
+            "handles_created": main_sum["handles_created"], "handles_reused": main_sum["handles_reused"],
+            "va_reserve_and_backfill_s": round(main_sum["va_reserve_and_backfill_s"], 3),
+            "roofline": roofline_from(res["stats"]),
+        }
+        if world == 1:
+            if not args.no_variants:
+                variants = {}
+                for name, mode, pool in (("lazy_no_backfill", "lazy", None), ("lazy_pool_16GiB", "lazy", 16384),
+                                         ("compat_pool_16GiB", "compat", 16384), ("compat_no_pool", "compat", 0)):
+                    try:
+                        # 8 warm-up batches are backed and released first: a 16 GiB pool then serves
+                        # all 8 timed batches from recycled handles
+                        r1 = measure(capi, device, 8, 8, mode, pool)
+                        s = summarize(r1, 8)
+                        variants[name] = {k: round(s[k], 3) for k in ("GBps", "p50_map_batch_ms", "us_per_page",
+                                                                       "unmap_GBps")}
+                        variants[name]["handles_reused"] = s["handles_reused"]
+                    except Exception as e:
+                        variants[name] = {"error": str(e)[:200]}
+                line["variants"] = variants
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
+                line["reference_hip_path_on_this_box"] = reference_on_box()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

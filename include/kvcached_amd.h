@@ -75,8 +75,13 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              VA unmapped (faster map/unmap, reads of unbacked VA fault).
  *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
  *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
- *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py). */
-enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4 };
+ *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py).
+ *   KVC_OPT_TLB_SHOOTDOWN  1 (default) = after every batch of VMM map/unmap calls force the driver to
+ *                              invalidate the GPU TLBs before anything touches the affected VA. On
+ *                              ROCm 7.2 / MI355X hipMemMap/hipMemUnmap alone leave stale translations
+ *                              behind; 0 only for measurements. */
+enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
+       KVC_OPT_TLB_SHOOTDOWN = 5 };
 int kvc_set_option(int opt, int64_t value);
 int64_t kvc_get_option(int opt);
 
@@ -90,6 +95,8 @@ typedef struct kvc_stats {
   double fill_ms;                             /* sum of event-timed kernel durations (profile on) */
   int64_t compact_launches, compact_bytes;    /* compact_blocks: bytes read + written */
   double compact_ms;
+  int64_t tlb_shootdowns;                     /* explicit GPU TLB invalidations (see KVC_OPT_TLB_SHOOTDOWN) */
+  int64_t shootdown_ns;                       /* host wall time spent in them */
 } kvc_stats_t;
 int kvc_get_stats(kvc_stats_t *out);
 int kvc_reset_stats(void);

@@ -21,7 +21,7 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
 KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, KVC_E_CALLBACK = 0, -1, -2, -3, -4, -5, -6
-OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE = 1, 2, 3, 4
+OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN = 1, 2, 3, 4, 5
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -39,7 +39,8 @@ class Stats(ctypes.Structure):
                 ("handles_created", _i64), ("handles_released", _i64), ("handles_reused", _i64),
                 ("map_calls", _i64), ("unmap_calls", _i64), ("map_ns", _i64), ("unmap_ns", _i64),
                 ("fill_launches", _i64), ("fill_bytes", _i64), ("fill_ms", ctypes.c_double),
-                ("compact_launches", _i64), ("compact_bytes", _i64), ("compact_ms", ctypes.c_double)]
+                ("compact_launches", _i64), ("compact_bytes", _i64), ("compact_ms", ctypes.c_double),
+                ("tlb_shootdowns", _i64), ("shootdown_ns", _i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -117,6 +117,7 @@ int kvc_set_option(int opt, int64_t value) {
   case KVC_OPT_ZERO_FILL: options().zero_fill = value; break;
   case KVC_OPT_POOL_BYTES: options().pool_bytes = value; break;
   case KVC_OPT_PROFILE: options().profile = value; break;
+  case KVC_OPT_TLB_SHOOTDOWN: options().tlb_shootdown = value; break;
   case 100: options().fill_variant = value; break;    // tuning only
   case 101: options().compact_variant = value; break; // tuning only
   default: return fail(KVC_E_INVALID, "unknown option");
@@ -129,6 +130,7 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_ZERO_FILL: return options().zero_fill;
   case KVC_OPT_POOL_BYTES: return options().pool_bytes;
   case KVC_OPT_PROFILE: return options().profile;
+  case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;
   default: return fail(KVC_E_INVALID, "unknown option");
@@ -151,6 +153,8 @@ int kvc_get_stats(kvc_stats_t *o) {
   o->fill_bytes = s.fill_bytes;
   o->compact_launches = s.compact_launches;
   o->compact_bytes = s.compact_bytes;
+  o->tlb_shootdowns = s.tlb_shootdowns;
+  o->shootdown_ns = s.shootdown_ns;
   std::lock_guard<std::mutex> g(s.mu);
   o->fill_ms = s.fill_ms;
   o->compact_ms = s.compact_ms;

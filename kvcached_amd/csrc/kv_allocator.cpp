@@ -1,6 +1,7 @@
 // kv_allocator.cpp — see kv_allocator.hpp.
 #include "kv_allocator.hpp"
 
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -24,6 +25,7 @@ void Stats::reset() {
   pages_mapped = pages_unmapped = 0;
   map_calls = unmap_calls = map_ns = unmap_ns = 0;
   fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
+  tlb_shootdowns = shootdown_ns = 0;
   vmm.created = vmm.released = vmm.reused = 0;
   std::lock_guard<std::mutex> g(mu);
   fill_ms = compact_ms = 0;
@@ -172,6 +174,18 @@ void GpuContext::compact(void *const *bases, size_t n_regions, const int64_t *sr
   }
 }
 
+void GpuContext::tlb_shootdown() {
+  if (!options().tlb_shootdown.load()) return;
+  const int64_t t0 = now_ns();
+  void *p = nullptr;
+  // 2 MiB is the smallest size ROCr does not serve from its sub-allocator, i.e. the cheapest
+  // allocation that reaches the kernel driver (measured: 4 KiB has no effect, 2 MiB ~0.22 ms).
+  HIP_CHECK(hipMalloc(&p, 2u << 20));
+  HIP_CHECK(hipFree(p));
+  stats().tlb_shootdowns++;
+  stats().shootdown_ns += now_ns() - t0;
+}
+
 void GpuContext::sync(hipStream_t s) {
   if (!s) s = stream_;
   HIP_CHECK(hipStreamSynchronize(s));
@@ -180,10 +194,14 @@ void GpuContext::sync(hipStream_t s) {
 
 // ------------------------------------------------------------------ registry
 void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contiguous_layout) {
-  std::lock_guard<std::mutex> g(g_mu);
+  std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> old; // destroyed after g_mu is released
+  std::unique_lock<std::mutex> g(g_mu);
   if (!g_allocators.empty()) {
     KVC_LOG(LOG_ERROR, "KvAllocator has been initialized. Re-initializing...");
-    g_allocators.clear();
+    old.swap(g_allocators);
+    g.unlock();
+    old.clear();
+    g.lock();
   }
   if (page_size > 0) {
     if (page_size % kBasePage != 0) // reference aborts here (allocator.cpp:84-90); we report it
@@ -195,6 +213,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", true) ? 1 : 0;
   options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
   options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 1024) << 20;
+  options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
   g_device = parse_device(dev_str);
   g_contiguous = contiguous_layout;
   if (g_device.is_gpu) {
@@ -202,16 +221,28 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     g_device.index = resolve_dev_index(g_device);
     context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
   }
-  g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout);
+  g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout,
+                                                  g_device.is_gpu ? context_for(g_device.index) : nullptr);
   g_initialized = true;
 }
 
 void KvAllocator::shutdown() {
-  std::lock_guard<std::mutex> g(g_mu);
-  g_allocators.clear();
-  for (auto &kv : g_contexts) kv.second->drain_pools();
-  g_contexts.clear();
-  g_initialized = false;
+  // Allocators unmap/release through their GpuContext and must not be destroyed under g_mu
+  // (region teardown is slow, and nothing below may re-enter the registry); contexts go last.
+  std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> victims;
+  {
+    std::lock_guard<std::mutex> g(g_mu);
+    victims.swap(g_allocators);
+    g_initialized = false;
+  }
+  victims.clear();
+  std::unordered_map<int, std::unique_ptr<GpuContext>> ctxs;
+  {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (g_allocators.empty()) ctxs.swap(g_contexts);
+  }
+  for (auto &kv : ctxs) kv.second->drain_pools();
+  ctxs.clear();
 }
 
 KvAllocator *KvAllocator::global(int64_t group_id) {
@@ -221,7 +252,7 @@ KvAllocator *KvAllocator::global(int64_t group_id) {
   if (g_allocators.empty()) throw InvalidError("KvAllocator::init() must be called first (init_kvcached)");
   // lazily created for an unseen group, with the device/layout of init() (allocator.cpp:101-114)
   auto &slot = g_allocators[group_id];
-  slot = std::make_unique<KvAllocator>(g_device, g_contiguous);
+  slot = std::make_unique<KvAllocator>(g_device, g_contiguous, g_device.is_gpu ? context_for(g_device.index) : nullptr);
   return slot.get();
 }
 
@@ -261,7 +292,8 @@ void device_synchronize() {
 }
 
 // ------------------------------------------------------------------ KvAllocator
-KvAllocator::KvAllocator(DeviceSpec dev, bool contiguous_layout) : dev_(dev), contiguous_(contiguous_layout) {
+KvAllocator::KvAllocator(DeviceSpec dev, bool contiguous_layout, GpuContext *ctx)
+    : dev_(dev), contiguous_(contiguous_layout), ctx_(ctx) {
   exportable_ = env_bool("KVCACHED_EXPORTABLE_HANDLES", false);
 }
 
@@ -300,7 +332,7 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // reference: FTensor::init_with_zero_ (ftensor.cpp:160-176) — one shared physical page aliased at every slot,
 // but with ONE ranged hipMemSetAccess instead of one per slot.
 void KvAllocator::backfill_all(KvRegion &r) {
-  auto acc = make_rw_access(gpu()->dev());
+  auto acc = make_rw_access(ctx_->dev());
   for (size_t i = 0; i < r.num_slots(); ++i)
     HIP_CHECK(hipMemMap(r.base + i * r.page_size, r.page_size, 0, zero_handle_, 0));
   HIP_CHECK(hipMemSetAccess(r.base, r.size, &acc, 1));
@@ -314,7 +346,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
     r.base = nullptr;
     return;
   }
-  GpuContext *ctx = gpu();
+  GpuContext *ctx = ctx_;
   if (ctx) (void)hipSetDevice(ctx->dev());
   // Tolerate stale mappings during teardown: log, do not throw (ftensor.cpp:78-98).
   bool whole = false;
@@ -356,7 +388,7 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
     aligned = ((size + ps - 1) / ps) * ps;
     KVC_LOG(LOG_WARNING, "Size %zu is not aligned to page size %zu, aligning to %zu", size, ps, aligned);
   }
-  GpuContext *ctx = dev_.is_gpu ? gpu() : nullptr;
+  GpuContext *ctx = ctx_;
   if (ctx) ctx->bind();
   const bool backfill = dev_.is_gpu && options().zero_backfill.load();
   const size_t region_page = contiguous_ ? ps * (size_t)num_layers * (size_t)num_kv_buffers : ps;
@@ -394,6 +426,7 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
     for (auto &r : layers_) out.push_back({r->base, r->size});
   }
   if (backfill) { // make the shared page really zero, through its first alias
+    ctx->tlb_shootdown();
     void *p = layers_[0]->base;
     ctx->zero_fill(&p, 1, region_page, nullptr);
     ctx->sync(nullptr);
@@ -494,7 +527,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     }
     return;
   }
-  GpuContext *ctx = gpu();
+  GpuContext *ctx = ctx_;
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   PhysPool *pool = ctx->pool(ps, exportable_);
@@ -510,10 +543,17 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   bool launched = false;
   size_t next_import = 0;
 
+  // Pages become usable in chunks: driver calls for <=256 slots, ONE TLB shootdown, then the fill kernel
+  // for exactly those slots runs on the GPU while the host issues the driver calls of the next chunk.
+  bool dirty_tlb = false; // driver calls issued since the last shootdown
   auto launch_pending = [&](bool all) {
     size_t i = 0;
     while (pending.size() - i >= (size_t)kMaxPtrsPerLaunch || (all && i < pending.size())) {
       size_t k = std::min<size_t>(kMaxPtrsPerLaunch, pending.size() - i);
+      if (dirty_tlb) {
+        ctx->tlb_shootdown();
+        dirty_tlb = false;
+      }
       ctx->zero_fill(pending.data() + i, k, ps, nullptr);
       launched = true;
       i += k;
@@ -523,6 +563,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   auto flush_run = [&]() {
     if (!run_len) return;
     HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    dirty_tlb = true;
     if (fill) {
       pending.insert(pending.end(), run_pages.begin(), run_pages.end());
       launch_pending(false);
@@ -561,6 +602,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     }
     flush_run();
     if (fill) launch_pending(true);
+    if (dirty_tlb) ctx->tlb_shootdown(); // nothing may reach the new pages through a stale translation
     if (launched) ctx->sync(nullptr);
   } catch (...) {
     // leave the regions as they were before this call; PageAllocator rolls the page ids back
@@ -577,6 +619,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (r.backfilled && hipMemMap(va, ps, 0, zero_handle_, 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
     }
     (void)hipGetLastError();
+    try {
+      ctx->tlb_shootdown();
+    } catch (...) {
+    }
     throw;
   }
   stats().pages_mapped += (int64_t)done.size();
@@ -595,7 +641,7 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
     return;
   }
-  GpuContext *ctx = gpu();
+  GpuContext *ctx = ctx_;
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   PhysPool *pool = ctx->pool(ps, exportable_);
@@ -634,17 +680,51 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
   }
   flush_run();
+  // stale entries would keep pointing at physical pages that now belong to the pool or to the driver
+  if (n_done) ctx->tlb_shootdown();
   stats().pages_unmapped += n_done;
 }
 
 // ------------------------------------------------------------------ TP shared pool
+// hipMemImportFromShareableHandle's `osHandle` convention differs between HIP runtimes: the one
+// bundled with PyTorch 2.10+rocm7.0 dereferences it as `int *` (passing the fd by value
+// segfaults inside amd::roc::Device::ImportShareableHSAHandle), ROCm 7.2's takes the fd by value
+// like CUDA. The pointer form is tried first: a by-value runtime reads the pointer's bits as a
+// (huge, invalid) fd number and fails cleanly, after which the by-value form is used.
+namespace {
+std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by value
+}
+static phys_handle_t import_posix_fd(int fd) {
+  if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
+  phys_handle_t h{};
+  int conv = g_import_convention.load();
+  if (conv != 2) {
+    alignas(8) static thread_local int slot;
+    slot = fd;
+    hipError_t st = hipMemImportFromShareableHandle(&h, static_cast<void *>(&slot), hipMemHandleTypePosixFileDescriptor);
+    if (st == hipSuccess) {
+      g_import_convention = 1;
+      return h;
+    }
+    (void)hipGetLastError();
+    int rt = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    // runtimes before 7.1 are known to dereference: never hand them a small integer as a pointer
+    if (conv == 1 || rt < 70100000) hip_check(st, "hipMemImportFromShareableHandle(&h, &fd, posix_fd)", __FILE__, __LINE__);
+  }
+  HIP_CHECK(hipMemImportFromShareableHandle(&h, reinterpret_cast<void *>(static_cast<uintptr_t>(fd)),
+                                            hipMemHandleTypePosixFileDescriptor));
+  g_import_convention = 2;
+  return h;
+}
+
 int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap) {
   std::lock_guard<std::mutex> g(mu_);
   if (!dev_.is_gpu) throw NoGpuError("export_mapped_slots needs a GPU device");
   if (!exportable_) throw InvalidError("handles are not exportable: set KVCACHED_EXPORTABLE_HANDLES=1 before init");
   auto slots = slots_for(offsets, n);
   if ((int64_t)slots.size() > cap) return (int)slots.size();
-  gpu()->bind();
+  ctx_->bind();
   int k = 0;
   for (auto &s : slots) {
     if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
@@ -661,12 +741,11 @@ bool KvAllocator::map_imported_slots(const offset_t *offsets, size_t n, const in
   if (num_layers_ == 0) return false;
   auto slots = slots_for(offsets, n);
   if (slots.size() != n_fds) throw InvalidError("fd count does not match the slot count of the offsets");
-  gpu()->bind();
+  ctx_->bind();
   std::vector<phys_handle_t> hs(n_fds);
   size_t i = 0;
   try {
-    for (; i < n_fds; ++i)
-      HIP_CHECK(hipMemImportFromShareableHandle(&hs[i], (void *)(uintptr_t)fds[i], hipMemHandleTypePosixFileDescriptor));
+    for (; i < n_fds; ++i) hs[i] = import_posix_fd(fds[i]);
   } catch (...) {
     for (size_t j = 0; j < i; ++j) (void)hipMemRelease(hs[j]);
     throw;

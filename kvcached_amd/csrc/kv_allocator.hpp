@@ -25,6 +25,7 @@ struct Options {
   std::atomic<int64_t> zero_fill{1};
   std::atomic<int64_t> pool_bytes{1024ll << 20};
   std::atomic<int64_t> profile{0};
+  std::atomic<int64_t> tlb_shootdown{1};
   std::atomic<int64_t> fill_variant{0};
   std::atomic<int64_t> compact_variant{0};
 };
@@ -35,6 +36,7 @@ struct Stats {
   std::atomic<int64_t> map_calls{0}, unmap_calls{0}, map_ns{0}, unmap_ns{0};
   std::atomic<int64_t> fill_launches{0}, fill_bytes{0};
   std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
+  std::atomic<int64_t> tlb_shootdowns{0}, shootdown_ns{0};
   std::mutex mu;
   double fill_ms = 0, compact_ms = 0;
   VmmCounters vmm;
@@ -58,6 +60,10 @@ public:
   void compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
                size_t block_bytes, hipStream_t s);
   void sync(hipStream_t s); // hipStreamSynchronize + harvest event timings
+  // Make the driver invalidate this GPU's TLBs. hipMemMap/hipMemUnmap/hipMemSetAccess do not do it
+  // on ROCm 7.2 (stale translations survive a remap: kvcached_amd/csrc/tools/remap_diag.cpp), but
+  // the KFD map ioctl behind an ordinary >= 2 MiB hipMalloc does.
+  void tlb_shootdown();
 
 private:
   struct Timed {
@@ -99,7 +105,7 @@ public:
   static GpuContext *gpu(); // context of the init device (nullptr on "cpu")
   static size_t page_size();
 
-  KvAllocator(DeviceSpec dev, bool contiguous_layout);
+  KvAllocator(DeviceSpec dev, bool contiguous_layout, GpuContext *ctx);
   ~KvAllocator();
 
   struct TensorDesc {
@@ -131,6 +137,7 @@ private:
 
   DeviceSpec dev_;
   bool contiguous_;
+  GpuContext *ctx_; // owned by the registry, outlives every allocator; nullptr on "cpu"
   bool unified_pool_ = false;
   bool exportable_ = false;
   int64_t num_layers_ = 0;

@@ -292,7 +292,7 @@ class CollectiveFanout:
     `src`'s offsets are authoritative. Backend nccl (= RCCL over xGMI) moves the vector through
     device memory, gloo through host memory."""
 
-    MAX_OFFSETS = 1021  # header + payload = 1024 int64 = 8 KiB, one fixed-size broadcast
+    MAX_OFFSETS = 4093  # header + payload = 4096 int64 = 32 KiB, one fixed-size broadcast
 
     def __init__(self, group=None, src: int = 0, device: Optional[str] = None):
         import torch

@@ -297,3 +297,94 @@ class OracleAdapter(Adapter):
         if self.h:
             self.lib.okvc_mgr_delete(self.h)
             self.h = None
+
+
+# --------------------------------------------------------------------------- product adapter
+PHYS_CAP = 1 << 30  # "unlimited" physical pages, kept small enough that bytes fit in size_t
+
+
+def set_product_phys_pages(pages: int, page_size: int, num_layers: int, num_kv_buffers: int) -> None:
+    """Make the product's get_avail_physical_pages() report exactly `pages` through the C ABI's
+    mem-info override: total=20 gives a headroom of size_t(20*0.05)=1 byte."""
+    from kvcached_amd import capi
+    pages = min(pages, PHYS_CAP)
+    capi.set_mem_info_override(pages * page_size * num_layers * num_kv_buffers + 1, 20)
+
+
+class ProductAdapter(Adapter):
+    """kvcached_amd.KVCacheManager (Python) over vmm_ops (pybind11) over the C ABI.
+
+    device="cpu": the reference's own host device path — bookkeeping only, map/unmap requests are
+    captured through the broadcast-callback hook exactly like oracle/gen_golden.py does with the
+    reference. device="cuda:0": requests are captured AND executed on the GPU (real hipMemMap +
+    zero fill), so the same golden traces also drive the HIP path."""
+
+    def __init__(self, num_blocks, block_size, cell_size, num_layers, world_size=1, reserve_null_block=False,
+                 num_kv_buffers=2, contiguous=False, phys_pages=1 << 40, group_id=0, device="cpu", execute=False,
+                 page_size=PAGE):
+        import kvcached_amd.kv_cache_manager as kcm
+        from kvcached_amd import vmm_ops
+        self.kcm, self.ops = kcm, vmm_ops
+        self.geom = (page_size, num_layers, num_kv_buffers)
+        kcm.CONTIGUOUS_LAYOUT = contiguous
+        vmm_ops.init_kvcached(device, page_size, contiguous)
+        self.real_phys = device != "cpu" and phys_pages >= PHYS_CAP
+        if not self.real_phys:
+            set_product_phys_pages(phys_pages, *self.geom)
+        self.events: List[List[Any]] = []
+        self.execute = execute
+        self.group_id = group_id
+        self.m = kcm.KVCacheManager(num_blocks, block_size, cell_size, num_layers, world_size=world_size,
+                                    reserve_null_block=reserve_null_block, num_kv_buffers=num_kv_buffers,
+                                    group_id=group_id)
+        pa = self.m.page_allocator
+        pa.set_should_use_worker_ipc_callback(lambda: True)
+        pa.set_broadcast_map_callback(self._on_map)
+        pa.set_broadcast_unmap_callback(self._on_unmap)
+        mem = num_blocks * block_size * cell_size
+        mem = (mem + 2 * page_size - 1) // (2 * page_size) * (2 * page_size)
+        self.tensors = vmm_ops.create_kv_tensors(mem * num_kv_buffers, 1, device, num_layers, num_kv_buffers,
+                                                 group_id, False)
+        assert self.m._post_init_done.wait(20), "_post_init did not finish"
+
+    def _on_map(self, ws, offs):
+        self.events.append([0, [int(o) for o in offs]])
+        if self.execute:
+            assert self.ops.map_to_kv_tensors(list(offs), self.group_id)
+
+    def _on_unmap(self, ws, offs):
+        self.events.append([1, [int(o) for o in offs]])
+        if self.execute:
+            assert self.ops.unmap_from_kv_tensors(list(offs), self.group_id)
+
+    def alloc(self, n): return self.m.alloc(n)
+    def free(self, ids): self.m.free(ids)
+    def try_to_reserve(self, n): return self.m.try_to_reserve(n)
+    def free_reserved(self): self.m.free_reserved()
+    def resize(self, mem): return self.m.resize(mem)
+    def trim(self): self.m.trim()
+
+    def set_phys(self, pages):
+        if not self.real_phys or pages < PHYS_CAP:
+            self.real_phys = False
+            set_product_phys_pages(pages, *self.geom)
+
+    def available_size(self): return self.m.available_size()
+
+    def snapshot(self):
+        import numpy as np
+        pa = self.m.page_allocator
+        t, u, p = [int(x) for x in np.fromfile("/dev/shm/" + pa._ipc_name(), dtype=np.int64)[:3]]
+        return [self.m.available_size(), pa.get_num_free_pages(), pa.get_num_inuse_pages(), pa.get_num_total_pages(),
+                pa.get_num_reserved_pages(), len(self.m.reserved_blocks), int(self.m.in_shrink), t, u, p]
+
+    def drain_events(self):
+        ev, self.events = self.events, []
+        return ev
+
+    def close(self):
+        from kvcached_amd import capi
+        self.m = None
+        self.tensors = None
+        self.ops.shutdown_kvcached()
+        capi.set_mem_info_override(0, 0)

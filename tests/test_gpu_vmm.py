@@ -1,0 +1,218 @@
+"""The reserve-then-back allocator on a real MI355X, driven through `vmm_ops` / the C ABI.
+
+Mirrors what the reference's GPU tests check (tests/test_paged_allocator_aliasing.py: unbacked VA
+aliases one zero page, backed pages are private) and adds what the north star adds: freshly backed
+pages read as zeros even when the physical handle is recycled and dirty.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MiB = 1 << 20
+PAGE = 2 * MiB
+DEV = "cuda:0"
+
+
+@pytest.fixture()
+def vmm():
+    """Fresh allocator per test (compat defaults: zero backfill on, zero fill on)."""
+    from kvcached_amd import capi, vmm_ops
+    state = {"ops": vmm_ops, "capi": capi}
+    yield state
+    vmm_ops.shutdown_kvcached()
+    capi.set_option(capi.OPT_ZERO_BACKFILL, 1)
+    capi.set_option(capi.OPT_ZERO_FILL, 1)
+
+
+def _setup(vmm, layers=2, per_layer=64 * MiB, contiguous=False, backfill=True, kv=2, unified=False):
+    ops, capi = vmm["ops"], vmm["capi"]
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if backfill else "false"
+    try:
+        ops.init_kvcached(DEV, PAGE, contiguous)
+    finally:
+        os.environ.pop("KVCACHED_ZERO_BACKFILL", None)
+    assert capi.get_option(capi.OPT_ZERO_BACKFILL) == int(backfill)
+    ts = ops.create_kv_tensors(per_layer, 2, DEV, layers, kv, 0, unified)
+    return ops, capi, ts
+
+
+def test_tensor_surface(vmm):
+    ops, capi, ts = _setup(vmm)
+    assert len(ts) == 2 and ops.kv_tensors_created()
+    for t in ts:
+        assert t.dtype == torch.int16 and t.device == torch.device(DEV) and t.numel() == 64 * MiB // 2
+        assert t.data_ptr() % PAGE == 0 and not t.requires_grad
+    assert ts[1].data_ptr() - ts[0].data_ptr() == 64 * MiB       # consecutive reservations behind the hint
+    assert capi.get_region_bases(0) == [ts[0].data_ptr(), ts[0].data_ptr() + 32 * MiB,
+                                        ts[1].data_ptr(), ts[1].data_ptr() + 32 * MiB]
+
+
+def test_unbacked_va_aliases_the_zero_page(vmm):
+    """Reference semantics (csrc/ftensor.cpp:160-176): reads of unbacked VA return zeros and all
+    unbacked pages are one physical page."""
+    ops, capi, ts = _setup(vmm)
+    k = ts[0].view(torch.int16)
+    epp = PAGE // 2
+    assert int(torch.count_nonzero(k[:4 * epp])) == 0
+    k[5] = 1234                       # write through page 0's alias ...
+    torch.cuda.synchronize()
+    assert int(k[3 * epp + 5]) == 1234  # ... is visible through page 3's alias
+    k[5] = 0
+    torch.cuda.synchronize()
+
+
+def test_map_gives_private_zeroed_pages_even_when_recycled(vmm):
+    ops, capi, ts = _setup(vmm)
+    epp = PAGE // 2
+    offs = [0, 3 * PAGE, 7 * PAGE]
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors(offs)
+    st = capi.get_stats()
+    assert st["pages_mapped"] == len(offs) * 2 * 2 and st["fill_bytes"] == st["pages_mapped"] * PAGE
+    # K slot and V slot (second half of the tensor) of every layer are backed, zero, and private
+    for li, t in enumerate(ts):
+        for half in (0, t.numel() // 2):
+            for j, o in enumerate(offs):
+                page = t[half + o // 2: half + o // 2 + epp]
+                assert int(torch.count_nonzero(page)) == 0
+                page.fill_(100 * li + 10 * j + (1 if half else 0) + 1)
+    torch.cuda.synchronize()
+    for li, t in enumerate(ts):
+        for half in (0, t.numel() // 2):
+            for j, o in enumerate(offs):
+                page = t[half + o // 2: half + o // 2 + epp]
+                assert bool((page == 100 * li + 10 * j + (1 if half else 0) + 1).all())
+    # neighbours are still the shared zero page
+    assert int(torch.count_nonzero(ts[0][epp:2 * epp])) == 0
+    # unmap (handles go to the pool, dirty), remap elsewhere: recycled and zero again
+    assert ops.unmap_from_kv_tensors(offs)
+    assert int(torch.count_nonzero(ts[0][:epp])) == 0               # back on the zero page
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([PAGE, 2 * PAGE, 4 * PAGE])
+    st = capi.get_stats()
+    assert st["handles_reused"] == 12 and st["handles_created"] == 0
+    for t in ts:
+        for half in (0, t.numel() // 2):
+            for o in (PAGE, 2 * PAGE, 4 * PAGE):
+                assert int(torch.count_nonzero(t[half + o // 2: half + o // 2 + epp])) == 0
+    assert ops.unmap_from_kv_tensors([PAGE, 2 * PAGE, 4 * PAGE])
+
+
+def test_double_map_and_unmapped_unmap_are_tolerated_like_the_reference(vmm):
+    ops, capi, ts = _setup(vmm)
+    assert ops.map_to_kv_tensors([0])
+    ts[0][:8] = 7
+    torch.cuda.synchronize()
+    assert ops.map_to_kv_tensors([0])             # logs "already mapped", still True (ftensor.cpp:104-107)
+    assert bool((ts[0][:8] == 7).all())           # and the existing page was not replaced
+    assert ops.unmap_from_kv_tensors([0])
+    assert ops.unmap_from_kv_tensors([0])         # logs "not mapped", still True
+
+
+def test_lazy_mode_without_backfill(vmm):
+    """KVCACHED_ZERO_BACKFILL=false: unbacked VA stays unmapped; backed pages behave the same."""
+    ops, capi, ts = _setup(vmm, backfill=False)
+    epp = PAGE // 2
+    assert ops.map_to_kv_tensors([2 * PAGE, 3 * PAGE])
+    page = ts[1][2 * epp:4 * epp]
+    assert int(torch.count_nonzero(page)) == 0
+    page.fill_(9)
+    torch.cuda.synchronize()
+    assert bool((ts[1][2 * epp:4 * epp] == 9).all())
+    assert ops.unmap_from_kv_tensors([2 * PAGE, 3 * PAGE])
+    assert ops.map_to_kv_tensors([2 * PAGE])
+    assert int(torch.count_nonzero(ts[1][2 * epp:3 * epp])) == 0
+    assert ops.unmap_from_kv_tensors([2 * PAGE])
+
+
+def test_contiguous_layout_compound_pages(vmm):
+    """One region for all layers; an offset backs page x layers x kv bytes in ONE mapping."""
+    layers = 4
+    ops, capi, ts = _setup(vmm, layers=layers, per_layer=32 * MiB, contiguous=True)
+    assert len(ts) == 1 and ts[0].numel() * 2 == 32 * MiB * layers
+    compound = PAGE * layers * 2
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([0, 2 * compound])
+    st = capi.get_stats()
+    assert st["pages_mapped"] == 2 and st["fill_bytes"] == 2 * compound
+    e = compound // 2
+    assert int(torch.count_nonzero(ts[0][:e])) == 0
+    ts[0][:e] = 3
+    ts[0][2 * e:3 * e] = 4
+    torch.cuda.synchronize()
+    assert bool((ts[0][:e] == 3).all()) and bool((ts[0][2 * e:3 * e] == 4).all())
+    assert int(torch.count_nonzero(ts[0][e:2 * e])) == 0
+    assert ops.unmap_from_kv_tensors([0, 2 * compound])
+
+
+def test_unified_pool_and_single_buffer_back_one_slot_per_layer(vmm):
+    ops, capi, ts = _setup(vmm, layers=3, per_layer=16 * MiB, kv=1, unified=True)
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([0, PAGE])
+    assert capi.get_stats()["pages_mapped"] == 2 * 3
+    assert ops.unmap_from_kv_tensors([0, PAGE])
+
+
+def test_large_batch_random_order(vmm):
+    """512 page ids x 2 layers x K/V = 2048 slots (4 GiB) in one call, shuffled: all zero, all private."""
+    import numpy as np
+    ops, capi, ts = _setup(vmm, layers=2, per_layer=2048 * MiB)
+    offs = [int(i) * PAGE for i in np.random.default_rng(0).permutation(512)]
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors(offs)
+    st = capi.get_stats()
+    assert st["pages_mapped"] == 2048 and st["fill_bytes"] == 2048 * PAGE
+    for t in ts:
+        assert int(torch.count_nonzero(t)) == 0
+    # a checksum of checksums: page p of tensor i holds the value 1 + (p mod 250) everywhere
+    epp = PAGE // 2
+    for t in ts:
+        v = t.view(-1, epp)
+        v.copy_((torch.arange(v.shape[0], device=DEV) % 250 + 1).to(torch.int16).unsqueeze(1).expand_as(v))
+    torch.cuda.synchronize()
+    for t in ts:
+        v = t.view(-1, epp)
+        want = (torch.arange(v.shape[0], device=DEV) % 250 + 1).to(torch.int64) * epp
+        assert torch.equal(v.to(torch.int64).sum(dim=1), want)
+    assert ops.unmap_from_kv_tensors(offs)
+    assert capi.get_stats()["pages_unmapped"] == 2048
+
+
+def test_mem_get_info_and_avail_physical_pages(vmm):
+    ops, capi, ts = _setup(vmm)
+    free, total = capi.mem_get_info()
+    f2, t2 = torch.cuda.mem_get_info(0)
+    assert total == t2 and abs(free - f2) < 2048 * MiB
+    pa = ops.PageAllocator(2, 64 * MiB // 2, PAGE, 1, 0, False, False, False, 2, 0,
+                           os.environ["KVCACHED_IPC_NAME"] + "_mi")
+    want = int((free - int(total * (1.0 - 0.95))) // PAGE) // 2 // 2
+    assert abs(pa.get_avail_physical_pages() - want) <= 64
+    del pa
+
+
+def test_export_import_same_process(vmm):
+    """Shared-pool plumbing: slots backed with exportable handles are exported as POSIX fds and
+    imported + mapped into a second group's VA; both views see the same bytes."""
+    ops, capi = vmm["ops"], vmm["capi"]
+    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    try:
+        ops.init_kvcached(DEV, PAGE, False)
+        a = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 2, 0, False)
+        b = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 2, 1, False)     # group 1 = the "peer"
+    finally:
+        os.environ.pop("KVCACHED_EXPORTABLE_HANDLES", None)
+    assert ops.map_to_kv_tensors([PAGE], 0)
+    fds = capi.export_mapped_slots([PAGE], 0)
+    assert len(fds) == 2 and all(fd > 2 for fd in fds)
+    capi.map_imported_slots([PAGE], fds, 1)
+    for fd in fds:
+        os.close(fd)
+    epp = PAGE // 2
+    a[0][epp:epp + 16] = 4321
+    torch.cuda.synchronize()
+    assert bool((b[0][epp:epp + 16] == 4321).all())
+    assert ops.unmap_from_kv_tensors([PAGE], 1)
+    assert ops.unmap_from_kv_tensors([PAGE], 0)
