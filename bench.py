@@ -43,56 +43,68 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--mode", choices=["compat", "lazy"], default="compat",
-                    help="compat: unbacked VA aliases a zero page like the reference (default); lazy: no backfill")
+    ap.add_argument("--mode", choices=["lazy", "compat"], default="lazy",
+                    help="lazy (library default on ROCm): unbacked VA stays unmapped; compat: unbacked VA aliases "
+                         "(sharded) zero pages like the reference")
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def batch_offsets(batch_index: int, seed: int = 0):
+def batch_offsets(batch_index: int, seed: int = 0, slot: int = PAGE):
+    """Offsets of one 2 GiB batch: 1024 shuffled 2 MiB slots (or 2 GiB / slot compound slots)."""
     import numpy as np
-    perm = np.random.default_rng(seed + batch_index).permutation(BATCH_PAGES)
-    base = batch_index * BATCH_PAGES
-    return [int(base + p) * PAGE for p in perm]
+    n = BATCH_PAGES * PAGE // slot
+    perm = np.random.default_rng(seed + batch_index).permutation(n)
+    base = batch_index * n
+    return [int(base + p) * slot for p in perm]
 
 
 class Pool:
     """One region of `window` batches, driven through the C ABI."""
 
-    def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0):
+    def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
+                 compound_layers: int = 0):
         self.capi, self.device, self.window = capi, device, window_batches
         os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
         if pool_mb is not None:
             os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
         else:
             os.environ.pop("KVCACHED_PHYS_POOL_MB", None)
-        capi.init(device, page, False)
         self.size = window_batches * BATCH_PAGES * page
         t0 = time.perf_counter()
-        # one layer, one buffer, unified pool: one 2 MiB slot per offset (the bench_vmm shape)
-        self.tensors = capi.create_kv_tensors(self.size, 1, device, 1, 1, group_id, True)
+        if compound_layers:
+            # contiguous layout: one region, slot = compound page (2 MiB x layers x K/V), e.g. 128 MiB for Llama-3-8B
+            capi.init(device, page, True)
+            self.slot = page * compound_layers * 2
+            self.tensors = capi.create_kv_tensors(self.size // compound_layers, 1, device, compound_layers, 2, group_id, False)
+        else:
+            # one layer, one buffer, unified pool: one 2 MiB slot per offset (the bench_vmm shape)
+            capi.init(device, page, False)
+            self.slot = page
+            self.tensors = capi.create_kv_tensors(self.size, 1, device, 1, 1, group_id, True)
         self.reserve_s = time.perf_counter() - t0
 
     def close(self):
         self.capi.shutdown()
 
 
-def run_steps(capi, mapper, first_batch: int, n: int):
+def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
     """n timed map+zero steps; returns per-step seconds."""
     per = []
     for i in range(n):
-        offs = batch_offsets(first_batch + i)
+        offs = batch_offsets(first_batch + i, slot=slot)
         t0 = time.perf_counter()
         mapper(offs)
         per.append(time.perf_counter() - t0)
     return per
 
 
-def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None):
+def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0):
     window = max(32, steps + warmup)  # >= 64 GiB of VA
-    pool = Pool(capi, device, window, mode, pool_mb)
+    pool = Pool(capi, device, window, mode, pool_mb, compound_layers=compound_layers)
+    slot = pool.slot
     try:
         if fanout is not None:
             mapper = lambda offs: fanout.map_to_kv_tensors(offs)     # noqa: E731  rank 0's offsets win
@@ -101,9 +113,9 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
             mapper, unmapper = capi.map_to_kv_tensors, capi.unmap_from_kv_tensors
         # warm-up: back W batches and give them back, so that code paths are warm and the idle-handle
         # pool holds what its cap allows (the steady state of an elastic pool)
-        run_steps(capi, mapper, 0, warmup)
+        run_steps(capi, mapper, 0, warmup, slot)
         for b in range(warmup):
-            unmapper(batch_offsets(b))
+            unmapper(batch_offsets(b, slot=slot))
         capi.set_option(capi.OPT_PROFILE, 1)
         capi.reset_stats()
         if barrier:
@@ -111,18 +123,19 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         if sync:
             sync()
         t0 = time.perf_counter()
-        per = run_steps(capi, mapper, warmup, steps)
+        per = run_steps(capi, mapper, warmup, steps, slot)
         if sync:
             sync()
         if barrier:
             barrier()
         elapsed = time.perf_counter() - t0
         st = capi.get_stats()
+        st["driver_ns"] = capi.get_driver_breakdown()
         capi.set_option(capi.OPT_PROFILE, 0)
         # give everything back (untimed for the headline, reported on its own)
         t1 = time.perf_counter()
         for b in range(warmup, warmup + steps):
-            unmapper(batch_offsets(b))
+            unmapper(batch_offsets(b, slot=slot))
         unmap_s = time.perf_counter() - t1
         return {"elapsed": elapsed, "per_step": per, "stats": st, "unmap_s": unmap_s, "reserve_s": pool.reserve_s,
                 "window_GiB": pool.size / GiB}
@@ -142,6 +155,8 @@ def summarize(res, steps, n_gpus=1):
         "unmap_GBps": (len(res["per_step"]) + 0) * bytes_per_step / max(res["unmap_s"], 1e-9) / 1e9,
         "handles_created": st["handles_created"], "handles_reused": st["handles_reused"],
         "va_reserve_and_backfill_s": res["reserve_s"],
+        "driver_us_per_page": {k: round(v / 1e3 / (steps * BATCH_PAGES), 2) for k, v in st.get("driver_ns", {}).items() if v},
+        "tlb_shootdown_us": round(st["shootdown_ns"] / 1e3 / max(1, st["tlb_shootdowns"]), 1),
     }
     return out
 
@@ -156,7 +171,7 @@ def roofline_from(st):
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("write_bytes_per_launch")
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     return {"kernel": "zero_fill_pages", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -201,48 +216,58 @@ def cpu_baseline():
 
 REF_SNIPPET = r"""
 import importlib.machinery, importlib.util, json, sys, time, torch
-so = sys.argv[1]
+so, steps, warmup = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 loader = importlib.machinery.ExtensionFileLoader("vmm_ops", so)
 spec = importlib.util.spec_from_loader("vmm_ops", loader)
 ref = importlib.util.module_from_spec(spec); loader.exec_module(ref)
-PAGE, N, B = 2 << 20, 1024, int(sys.argv[2])
+PAGE, N = 2 << 20, 1024
 import numpy as np
+window = max(32, steps + warmup)
+offs = lambda b: [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
 ref.init_kvcached("cuda:0", PAGE, False)
 t0 = time.perf_counter()
-ref.create_kv_tensors(B * N * PAGE, 1, "cuda:0", 1, 1, 0, True)
+ref.create_kv_tensors(window * N * PAGE, 1, "cuda:0", 1, 1, 0, True)
 t_create = time.perf_counter() - t0
-per = []
-for b in range(B):
-    offs = [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
-    t0 = time.perf_counter(); assert ref.map_to_kv_tensors(offs); per.append(time.perf_counter() - t0)
+for b in range(warmup):
+    assert ref.map_to_kv_tensors(offs(b))
+for b in range(warmup):
+    assert ref.unmap_from_kv_tensors(offs(b))
 torch.cuda.synchronize()
+per = []
+t_all = time.perf_counter()
+for b in range(warmup, warmup + steps):
+    t0 = time.perf_counter(); assert ref.map_to_kv_tensors(offs(b)); per.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t_all
 tu = time.perf_counter()
-for b in range(B):
-    offs = [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
-    assert ref.unmap_from_kv_tensors(offs)
+for b in range(warmup, warmup + steps):
+    assert ref.unmap_from_kv_tensors(offs(b))
 tu = time.perf_counter() - tu
-per = per[1:] if len(per) > 2 else per
-print(json.dumps({"GBps": N * PAGE / (sum(per) / len(per)) / 1e9, "p50_map_batch_ms": sorted(per)[len(per)//2] * 1e3,
-                  "us_per_page": sum(per) / len(per) / N * 1e6, "unmap_GBps": B * N * PAGE / tu / 1e9,
-                  "va_reserve_and_backfill_s": t_create, "batches": B}))
+print(json.dumps({"GBps": steps * N * PAGE / t_all / 1e9, "p50_map_batch_ms": sorted(per)[len(per)//2] * 1e3,
+                  "first_batch_ms": per[0] * 1e3, "last_batch_ms": per[-1] * 1e3,
+                  "us_per_page": t_all / steps / N * 1e6, "unmap_GBps": steps * N * PAGE / tu / 1e9,
+                  "va_reserve_and_backfill_s": t_create, "steps": steps, "warmup": warmup, "window_GiB": window * 2}))
 ref.shutdown_kvcached()
 """
 
 
-def reference_on_box():
+def reference_on_box(steps, warmup):
     """The REAL reference (oracle/_ref/vmm_ops.so, compiled from its own sources in the build
-    container) running its own HIP path on this GPU: same batch shape, its FTensor::map per page
-    (unmap zero alias + hipMemCreate + hipMemMap + hipMemSetAccess, no zero fill). Context only."""
+    container) running its own HIP path on this GPU on the SAME workload (same window, warm-up, steps and
+    offsets): its FTensor::map per page = unmap zero alias + hipMemCreate + hipMemMap + hipMemSetAccess,
+    no zero fill, no TLB invalidation (so its pages are not even reliably private).
+    Context only."""
     so = os.path.join(REPO, "oracle", "_ref", "vmm_ops.so")
     if not os.path.exists(so):
         return None
     try:
-        out = subprocess.run([sys.executable, "-c", REF_SNIPPET, so, "6"], capture_output=True, text=True, timeout=300)
+        out = subprocess.run([sys.executable, "-c", REF_SNIPPET, so, str(steps), str(warmup)], capture_output=True,
+                             text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:]}
         d = json.loads(line[-1])
-        d["what"] = "reference csrc (KVCACHED_USE_HIP) map_to_kv_tensors, 1024 x 2 MiB per call, no zero fill"
+        d["what"] = "reference csrc (KVCACHED_USE_HIP) map_to_kv_tensors on the same workload, no zero fill"
         return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
     except Exception as e:  # never let the context number break the bench line
         return {"error": str(e)[:200]}
@@ -308,27 +333,33 @@ def main():
             "unmap_GBps": round(main_sum["unmap_GBps"], 2),
             "handles_created": main_sum["handles_created"], "handles_reused": main_sum["handles_reused"],
             "va_reserve_and_backfill_s": round(main_sum["va_reserve_and_backfill_s"], 3),
+            "driver_us_per_page": main_sum["driver_us_per_page"], "tlb_shootdown_us": main_sum["tlb_shootdown_us"],
             "roofline": roofline_from(res["stats"]),
         }
         if world == 1:
             if not args.no_variants:
                 variants = {}
-                for name, mode, pool in (("lazy_no_backfill", "lazy", None), ("lazy_pool_16GiB", "lazy", 16384),
-                                         ("compat_pool_16GiB", "compat", 16384), ("compat_no_pool", "compat", 0)):
+                for name, mode, pool, comp in (("lazy_pool_64GiB_all_recycled", "lazy", 65536, 0),
+                                               ("lazy_no_pool_all_created", "lazy", 0, 0),
+                                               ("compat_sharded_zero_pages", "compat", None, 0),
+                                               ("compat_pool_64GiB_all_recycled", "compat", 65536, 0),
+                                               ("lazy_contiguous_layout_128MiB_compound_pages", "lazy", None, 32)):
                     try:
-                        # 8 warm-up batches are backed and released first: a 16 GiB pool then serves
-                        # all 8 timed batches from recycled handles
-                        r1 = measure(capi, device, 8, 8, mode, pool)
+                        # warm-up backs and releases as many batches as are timed: a large pool then serves
+                        # every timed batch from recycled handles (the steady state of an elastic pool)
+                        r1 = measure(capi, device, 8, 8, mode, pool, compound_layers=comp)
                         s = summarize(r1, 8)
-                        variants[name] = {k: round(s[k], 3) for k in ("GBps", "p50_map_batch_ms", "us_per_page",
-                                                                       "unmap_GBps")}
-                        variants[name]["handles_reused"] = s["handles_reused"]
+                        variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
+                                          for k in ("GBps", "p50_map_batch_ms", "us_per_page", "unmap_GBps",
+                                                    "handles_created", "handles_reused", "driver_us_per_page")}
+                        rf = roofline_from(r1["stats"])
+                        variants[name]["fill_GBps"] = rf["achieved"] if rf else None
                     except Exception as e:
                         variants[name] = {"error": str(e)[:200]}
                 line["variants"] = variants
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
-                line["reference_hip_path_on_this_box"] = reference_on_box()
+                line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

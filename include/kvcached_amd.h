@@ -36,7 +36,8 @@ enum {
   KVC_E_NO_PAGES = -3, /* "No free pages left" (csrc/page_allocator.cpp:201) */
   KVC_E_RUNTIME = -4,  /* any other std::runtime_error of the reference */
   KVC_E_NO_GPU = -5,   /* a GPU-only entry point was called on the "cpu" device / without a GPU */
-  KVC_E_CALLBACK = -6  /* a broadcast callback reported failure */
+  KVC_E_CALLBACK = -6, /* a broadcast callback reported failure */
+  KVC_E_NOT_CREATED = -7 /* map/unmap before create_kv_tensors: the reference logs and returns false (allocator.cpp:163-166) */
 };
 
 const char *kvc_last_error(void);
@@ -70,9 +71,10 @@ int kvc_map_to_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 
 /* Runtime knobs (also read once from the environment at kvc_init):
- *   KVC_OPT_ZERO_BACKFILL  1 = every unbacked VA page aliases one shared zero page, as the
- *                              reference does (csrc/ftensor.cpp:160-176); 0 = leave unbacked
- *                              VA unmapped (faster map/unmap, reads of unbacked VA fault).
+ *   KVC_OPT_ZERO_BACKFILL  1 = every unbacked VA page aliases a zero page, as the reference does
+ *                              (csrc/ftensor.cpp:160-176; sharded); 0 (default on
+ *                              ROCm) = leave unbacked VA unmapped: reads of unbacked VA fault
+ *                              instead of returning zeros, map/unmap/create stay O(1) in the VA size.
  *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
  *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
  *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py).
@@ -100,6 +102,10 @@ typedef struct kvc_stats {
 } kvc_stats_t;
 int kvc_get_stats(kvc_stats_t *out);
 int kvc_reset_stats(void);
+/* Diagnostics: host nanoseconds spent inside each driver call class since the last reset, out[8] =
+ * {unmap zero alias, handle acquire (pool / hipMemCreate), hipMemMap, hipMemSetAccess, hipMemUnmap,
+ *  handle release, re-alias, wait for the fill kernel}. */
+int kvc_get_driver_breakdown(int64_t *out8);
 
 /* hipMemGetInfo of the allocator's device; kvc_set_mem_info_override(free,total) replaces
  * the reading (tests and the "cpu" device), (0,0) removes the override. */

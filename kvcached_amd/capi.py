@@ -21,6 +21,7 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
 KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, KVC_E_CALLBACK = 0, -1, -2, -3, -4, -5, -6
+KVC_E_NOT_CREATED = -7
 OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN = 1, 2, 3, 4, 5
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "kvc_get_option": (_i64, [_int]),
     "kvc_get_stats": (_int, [ctypes.POINTER(Stats)]),
     "kvc_reset_stats": (_int, []),
+    "kvc_get_driver_breakdown": (_int, [_I64P]),
     "kvc_mem_get_info": (_int, [_SZP, _SZP]),
     "kvc_set_mem_info_override": (_int, [_sz, _sz]),
     "kvc_page_new": (_vp, [_i64, _i64]),
@@ -175,6 +177,16 @@ def get_stats() -> dict:
     s = Stats()
     check(lib.kvc_get_stats(ctypes.byref(s)))
     return s.as_dict()
+
+
+DRIVER_CALLS = ("unmap_alias", "acquire", "map", "set_access", "unmap", "release", "realias", "fill_sync")
+
+
+def get_driver_breakdown() -> dict:
+    """Host ns inside each driver-call class since the last reset_stats()."""
+    out = (ctypes.c_int64 * 8)()
+    check(lib.kvc_get_driver_breakdown(out))
+    return dict(zip(DRIVER_CALLS, (int(x) for x in out)))
 
 
 def reset_stats() -> None:

@@ -100,14 +100,14 @@ int kvc_get_device(int *is_gpu, int *index) {
 int kvc_map_to_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id) {
   return guarded([&]() -> int {
     return KvAllocator::global(group_id)->map_to_kv_tensors(offsets, n) ? KVC_OK
-                                                                         : fail(KVC_E_INVALID, "KV tensors are not created");
+                                                                         : fail(KVC_E_NOT_CREATED, "KV tensors are not created");
   });
 }
 int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id) {
   return guarded([&]() -> int {
     return KvAllocator::global(group_id)->unmap_from_kv_tensors(offsets, n)
                ? KVC_OK
-               : fail(KVC_E_INVALID, "KV tensors are not created");
+               : fail(KVC_E_NOT_CREATED, "KV tensors are not created");
   });
 }
 
@@ -118,6 +118,8 @@ int kvc_set_option(int opt, int64_t value) {
   case KVC_OPT_POOL_BYTES: options().pool_bytes = value; break;
   case KVC_OPT_PROFILE: options().profile = value; break;
   case KVC_OPT_TLB_SHOOTDOWN: options().tlb_shootdown = value; break;
+  case 102: options().access_run_slots = value; break; // tuning only
+  case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 100: options().fill_variant = value; break;    // tuning only
   case 101: options().compact_variant = value; break; // tuning only
   default: return fail(KVC_E_INVALID, "unknown option");
@@ -131,6 +133,8 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_POOL_BYTES: return options().pool_bytes;
   case KVC_OPT_PROFILE: return options().profile;
   case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
+  case 102: return options().access_run_slots;
+  case 103: return options().zero_alias_fanout;
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;
   default: return fail(KVC_E_INVALID, "unknown option");
@@ -158,6 +162,13 @@ int kvc_get_stats(kvc_stats_t *o) {
   std::lock_guard<std::mutex> g(s.mu);
   o->fill_ms = s.fill_ms;
   o->compact_ms = s.compact_ms;
+  return KVC_OK;
+}
+int kvc_get_driver_breakdown(int64_t *o) {
+  if (!o) return fail(KVC_E_INVALID, "NULL output");
+  Stats &s = stats();
+  o[0] = s.t_unmap_alias; o[1] = s.t_acquire; o[2] = s.t_map; o[3] = s.t_access;
+  o[4] = s.t_unmap; o[5] = s.t_release; o[6] = s.t_realias; o[7] = s.t_sync;
   return KVC_OK;
 }
 int kvc_reset_stats(void) {
@@ -359,7 +370,7 @@ int kvc_export_mapped_slots(const int64_t *offsets, size_t n, int64_t group_id, 
 int kvc_map_imported_slots(const int64_t *offsets, size_t n, int64_t group_id, const int *fds, size_t n_fds) {
   return guarded([&]() -> int {
     return KvAllocator::global(group_id)->map_imported_slots(offsets, n, fds, n_fds) ? KVC_OK
-                                                                                      : fail(KVC_E_INVALID, "KV tensors are not created");
+                                                                                      : fail(KVC_E_NOT_CREATED, "KV tensors are not created");
   });
 }
 

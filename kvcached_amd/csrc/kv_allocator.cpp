@@ -26,6 +26,7 @@ void Stats::reset() {
   map_calls = unmap_calls = map_ns = unmap_ns = 0;
   fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
   tlb_shootdowns = shootdown_ns = 0;
+  t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
   vmm.created = vmm.released = vmm.reused = 0;
   std::lock_guard<std::mutex> g(mu);
   fill_ms = compact_ms = 0;
@@ -210,10 +211,15 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     g_page_size = page_size;
   }
   // environment knobs, read once per init
-  options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", true) ? 1 : 0;
+  // Default OFF on ROCm: with every unbacked slot aliased, each hipMemCreate costs O(mappings in the
+  // process) — ~2 ms at the 147k slots of a 288 GiB reservation. Opt in with
+  // KVCACHED_ZERO_BACKFILL=true for the reference's "stray reads return zeros" semantics.
+  options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", false) ? 1 : 0;
   options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
-  options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 1024) << 20;
+  options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 4096) << 20;
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
+  options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
+  options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   g_device = parse_device(dev_str);
   g_contiguous = contiguous_layout;
   if (g_device.is_gpu) {
@@ -301,10 +307,6 @@ KvAllocator::~KvAllocator() {
   std::lock_guard<std::mutex> g(mu_);
   for (auto &r : layers_) destroy_region(*r);
   layers_.clear();
-  if (have_zero_) {
-    (void)hipMemRelease(zero_handle_);
-    have_zero_ = false;
-  }
 }
 
 std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size_t size, size_t page_size) {
@@ -329,14 +331,42 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
   return r;
 }
 
-// reference: FTensor::init_with_zero_ (ftensor.cpp:160-176) — one shared physical page aliased at every slot,
-// but with ONE ranged hipMemSetAccess instead of one per slot.
+// reference: FTensor::init_with_zero_ (ftensor.cpp:160-176) — every unbacked slot aliases a physical
+// page of zeros so that stray reads do not fault. The reference uses ONE such page for the whole
+// reservation; on ROCm hipMemUnmap of an alias costs O(aliases of that handle) (~6 ns each: 37 us
+// per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
+// the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
 void KvAllocator::backfill_all(KvRegion &r) {
   auto acc = make_rw_access(ctx_->dev());
-  for (size_t i = 0; i < r.num_slots(); ++i)
-    HIP_CHECK(hipMemMap(r.base + i * r.page_size, r.page_size, 0, zero_handle_, 0));
-  HIP_CHECK(hipMemSetAccess(r.base, r.size, &acc, 1));
+  auto prop = make_alloc_prop(ctx_->dev(), false);
+  r.fanout = (size_t)std::max<int64_t>(1, options().zero_alias_fanout.load());
+  const size_t n_zero = (r.num_slots() + r.fanout - 1) / r.fanout;
+  r.zero.assign(n_zero, phys_handle_t{});
+  size_t made = 0;
+  try {
+    for (; made < n_zero; ++made) HIP_CHECK(hipMemCreate(&r.zero[made], r.page_size, &prop, 0));
+    const size_t run = (size_t)std::max<int64_t>(1, options().access_run_slots.load());
+    for (size_t i = 0; i < r.num_slots(); ++i)
+      HIP_CHECK(hipMemMap(r.base + i * r.page_size, r.page_size, 0, r.zero_of(i), 0));
+    for (size_t i = 0; i < r.num_slots(); i += run) {
+      size_t k = std::min(run, r.num_slots() - i);
+      HIP_CHECK(hipMemSetAccess(r.base + i * r.page_size, k * r.page_size, &acc, 1));
+    }
+  } catch (...) {
+    (void)hipMemUnmap(r.base, r.size);
+    for (size_t j = 0; j < made; ++j) (void)hipMemRelease(r.zero[j]);
+    r.zero.clear();
+    (void)hipGetLastError();
+    throw;
+  }
   r.backfilled = true;
+  // the driver hands out zeroed memory today, but that is not a documented guarantee: fill each
+  // zero page once, through its first alias
+  ctx_->tlb_shootdown();
+  std::vector<void *> firsts;
+  for (size_t z = 0; z < n_zero; ++z) firsts.push_back(r.base + z * r.fanout * r.page_size);
+  ctx_->zero_fill(firsts.data(), firsts.size(), r.page_size, nullptr);
+  ctx_->sync(nullptr);
 }
 
 void KvAllocator::destroy_region(KvRegion &r) {
@@ -366,6 +396,10 @@ void KvAllocator::destroy_region(KvRegion &r) {
     stats().vmm.released++;
     r.mapped[i] = 0;
   }
+  if (r.backfilled && !whole) // aliases that could not be dropped in one call
+    for (size_t i = 0; i < r.num_slots(); ++i) (void)hipMemUnmap(r.base + i * r.page_size, r.page_size);
+  for (auto z : r.zero) (void)hipMemRelease(z);
+  r.zero.clear();
   hipError_t st = hipMemAddressFree(r.base, r.size);
   if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemAddressFree during cleanup failed: %s", hipGetErrorString(st));
   (void)hipGetLastError();
@@ -393,14 +427,6 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
   const bool backfill = dev_.is_gpu && options().zero_backfill.load();
   const size_t region_page = contiguous_ ? ps * (size_t)num_layers * (size_t)num_kv_buffers : ps;
 
-  if (backfill && (!have_zero_ || zero_bytes_ != region_page)) {
-    if (have_zero_) (void)hipMemRelease(zero_handle_);
-    auto prop = make_alloc_prop(ctx->dev(), false);
-    HIP_CHECK(hipMemCreate(&zero_handle_, region_page, &prop, 0));
-    zero_bytes_ = region_page;
-    have_zero_ = true;
-  }
-
   std::vector<TensorDesc> out;
   if (contiguous_) {
     // one region for all layers; slot = compound page (page x layers x kv buffers), allocator.cpp:139-147
@@ -424,12 +450,6 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
       }
     }
     for (auto &r : layers_) out.push_back({r->base, r->size});
-  }
-  if (backfill) { // make the shared page really zero, through its first alias
-    ctx->tlb_shootdown();
-    void *p = layers_[0]->base;
-    ctx->zero_fill(&p, 1, region_page, nullptr);
-    ctx->sync(nullptr);
   }
   num_layers_ = num_layers;
   num_kv_buffers_ = num_kv_buffers;
@@ -533,7 +553,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   PhysPool *pool = ctx->pool(ps, exportable_);
   const auto acc = make_rw_access(ctx->dev());
   const bool fill = options().zero_fill.load() && !imported;
-  constexpr size_t kMaxRunBytes = 1ull << 30;
+  const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
 
   std::vector<Slot> done;
   done.reserve(slots.size());
@@ -562,7 +582,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   };
   auto flush_run = [&]() {
     if (!run_len) return;
+    const int64_t ta = now_ns();
     HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    stats().t_access += now_ns() - ta;
     dirty_tlb = true;
     if (fill) {
       pending.insert(pending.end(), run_pages.begin(), run_pages.end());
@@ -581,13 +603,20 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
         continue;
       }
       char *va = r.base + s.index * ps;
+      int64_t t0 = now_ns();
       if (r.backfilled) HIP_CHECK(hipMemUnmap(va, ps));
+      int64_t t1 = now_ns();
       bool recycled = false;
       phys_handle_t h = imported ? (*imported)[next_import++] : pool->acquire(&recycled);
+      int64_t t2 = now_ns();
       hipError_t st = hipMemMap(va, ps, 0, h, 0);
+      int64_t t3 = now_ns();
+      stats().t_unmap_alias += t1 - t0;
+      stats().t_acquire += t2 - t1;
+      stats().t_map += t3 - t2;
       if (st != hipSuccess) {
         if (!imported) pool->release(h);
-        if (r.backfilled && hipMemMap(va, ps, 0, zero_handle_, 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
+        if (r.backfilled && hipMemMap(va, ps, 0, r.zero_of(s.index), 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
         HIP_CHECK(st);
       }
       r.handle[s.index] = h;
@@ -603,7 +632,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     flush_run();
     if (fill) launch_pending(true);
     if (dirty_tlb) ctx->tlb_shootdown(); // nothing may reach the new pages through a stale translation
+    const int64_t ts = now_ns();
     if (launched) ctx->sync(nullptr);
+    stats().t_sync += now_ns() - ts;
   } catch (...) {
     // leave the regions as they were before this call; PageAllocator rolls the page ids back
     if (launched) (void)hipStreamSynchronize(ctx->stream());
@@ -616,7 +647,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       else
         (void)hipMemRelease(r.handle[it->index]);
       r.mapped[it->index] = 0;
-      if (r.backfilled && hipMemMap(va, ps, 0, zero_handle_, 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
+      if (r.backfilled && hipMemMap(va, ps, 0, r.zero_of(it->index), 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
     }
     (void)hipGetLastError();
     try {
@@ -648,6 +679,7 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
   const auto acc = make_rw_access(ctx->dev());
   char *run_start = nullptr;
   size_t run_len = 0;
+  const size_t max_run = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
   auto flush_run = [&]() {
     if (!run_len) return;
     HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
@@ -661,9 +693,13 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
       continue;
     }
     char *va = r.base + s.index * ps;
+    const int64_t t0 = now_ns();
     HIP_CHECK(hipMemUnmap(va, ps));
+    const int64_t t1 = now_ns();
+    stats().t_unmap += t1 - t0;
     if (r.mapped[s.index] == 1) {
       pool->release(r.handle[s.index]);
+      stats().t_release += now_ns() - t1;
     } else {
       hipError_t st = hipMemRelease(r.handle[s.index]);
       if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
@@ -671,8 +707,10 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     r.mapped[s.index] = 0;
     ++n_done;
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
-      HIP_CHECK(hipMemMap(va, ps, 0, zero_handle_, 0));
-      if (!(run_len && va == run_start + run_len)) {
+      const int64_t tr = now_ns();
+      HIP_CHECK(hipMemMap(va, ps, 0, r.zero_of(s.index), 0));
+      stats().t_realias += now_ns() - tr;
+      if (!(run_len && va == run_start + run_len && run_len < max_run)) {
         flush_run();
         run_start = va;
       }

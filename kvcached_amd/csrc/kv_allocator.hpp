@@ -21,11 +21,13 @@
 namespace kvc {
 
 struct Options {
-  std::atomic<int64_t> zero_backfill{1};
+  std::atomic<int64_t> zero_backfill{0};
   std::atomic<int64_t> zero_fill{1};
-  std::atomic<int64_t> pool_bytes{1024ll << 20};
+  std::atomic<int64_t> pool_bytes{4096ll << 20};
   std::atomic<int64_t> profile{0};
   std::atomic<int64_t> tlb_shootdown{1};
+  std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
+  std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
   std::atomic<int64_t> fill_variant{0};
   std::atomic<int64_t> compact_variant{0};
 };
@@ -37,6 +39,8 @@ struct Stats {
   std::atomic<int64_t> fill_launches{0}, fill_bytes{0};
   std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
   std::atomic<int64_t> tlb_shootdowns{0}, shootdown_ns{0};
+  // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
+  std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
   std::mutex mu;
   double fill_ms = 0, compact_ms = 0;
   VmmCounters vmm;
@@ -88,7 +92,10 @@ struct KvRegion {
   size_t size = 0;
   size_t page_size = 0;
   bool on_gpu = false;
-  bool backfilled = false;             // every unbacked slot currently aliases the zero page
+  bool backfilled = false;             // every unbacked slot currently aliases a zero page
+  std::vector<phys_handle_t> zero;     // zero pages of this region; slot i aliases zero[i / fanout]
+  size_t fanout = 1;
+  phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page
   size_t num_slots() const { return size / page_size; }
@@ -145,9 +152,6 @@ private:
   size_t tensor_bytes_per_layer_ = 0;
   std::mutex mu_;
   std::vector<std::unique_ptr<KvRegion>> layers_; // per-layer regions, or ONE region in contiguous layout
-  phys_handle_t zero_handle_{};
-  size_t zero_bytes_ = 0;
-  bool have_zero_ = false;
 };
 
 // hipMemGetInfo of the init device, or the test override.

@@ -89,14 +89,14 @@ bool kv_tensors_created(int64_t group_id) {
 bool map_to_kv_tensors(const std::vector<int64_t> &offsets, int64_t group_id) {
   py::gil_scoped_release nogil;
   int rc = kvc_map_to_kv_tensors(offsets.data(), offsets.size(), group_id);
-  if (rc == KVC_E_INVALID) return false; // "KV tensors are not created": the reference logs and returns False
+  if (rc == KVC_E_NOT_CREATED) return false; // the reference logs and returns False
   check(rc);
   return true;
 }
 bool unmap_from_kv_tensors(const std::vector<int64_t> &offsets, int64_t group_id) {
   py::gil_scoped_release nogil;
   int rc = kvc_unmap_from_kv_tensors(offsets.data(), offsets.size(), group_id);
-  if (rc == KVC_E_INVALID) return false;
+  if (rc == KVC_E_NOT_CREATED) return false;
   check(rc);
   return true;
 }

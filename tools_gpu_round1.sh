@@ -1,22 +1,28 @@
 #!/bin/bash
-# one GPU session: parity tests, smoke, bench, kernel-trace profile
+# one GPU session: parity tests, smoke, bench, kernel-trace profile, PMC passes
+# usage: ./tools_gpu_round1.sh [nopytest]
 set -o pipefail
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-echo "== pytest -m gpu"
-[ "$1" = "nopytest" ] || timeout -k 10 900 python -u -m pytest tests -m gpu -x -v --timeout=240 > gpurun_out/pytest_gpu.log 2>&1; rc=$?
-[ "$1" = "nopytest" ] && rc=0
-tail -5 gpurun_out/pytest_gpu.log; echo "pytest rc=$rc"
-[ $rc -ne 0 ] && exit $rc
+if [ "$1" != "nopytest" ]; then
+  echo "== pytest -m gpu"
+  timeout -k 10 900 python -u -m pytest tests -m gpu -x -v --timeout=240 > gpurun_out/pytest_gpu.log 2>&1; rc=$?
+  tail -4 gpurun_out/pytest_gpu.log; echo "pytest rc=$rc"
+  [ $rc -ne 0 ] && exit $rc
+fi
 echo "== smoke"
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; rc=$?
-tail -3 gpurun_out/smoke.log; echo "smoke rc=$rc"
+tail -1 gpurun_out/smoke.log; echo "smoke rc=$rc"
 [ $rc -ne 0 ] && exit $rc
 echo "== bench"
 timeout -k 10 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; rc=$?
-tail -2 gpurun_out/bench.log; tail -5 gpurun_out/bench.err; echo "bench rc=$rc"
+tail -1 gpurun_out/bench.log; grep -v amdgpu.ids gpurun_out/bench.err | tail -5; echo "bench rc=$rc"
 [ $rc -ne 0 ] && exit $rc
-echo "== rocprofv3 kernel trace"
+echo "== rocprofv3 kernel trace (same command as the bench, context legs off)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-variants --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1; rc=$?
-tail -3 gpurun_out/prof_kt.log; echo "rocprof rc=$rc"
-find gpurun_out/prof_kt -name "*stats*" | head
+grep '"metric"' gpurun_out/prof_kt.log | cut -c1-300; echo "rocprof kt rc=$rc"
+echo "== rocprofv3 PMC WRITE_SIZE (own pass)"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_pmc_w -- python3 bench.py --no-variants --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/prof_pmc_w.log 2>&1; echo "pmc write rc=$?"
+echo "== rocprofv3 PMC FETCH_SIZE (own pass)"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_pmc_r -- python3 bench.py --no-variants --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/prof_pmc_r.log 2>&1; echo "pmc fetch rc=$?"
+find gpurun_out/prof_kt gpurun_out/prof_pmc_w gpurun_out/prof_pmc_r -name "*.csv" | head -20
