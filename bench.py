@@ -285,25 +285,30 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_{os.getpid()}")
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    local_rank %= max(1, torch.cuda.device_count())   # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     from kvcached_amd import capi
 
     fanout = barrier = None
     sync = torch.cuda.synchronize
+    backend = os.environ.get("KVC_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N>1 code path on one GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
         from kvcached_amd.tp_ipc_util import CollectiveFanout
-        fanout = CollectiveFanout(device=device)
+        fanout = CollectiveFanout(device=device if backend == "nccl" else "cpu")
         barrier = dist.barrier
 
     res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync)
     elapsed = res["elapsed"]
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         res["elapsed"] = elapsed
@@ -326,7 +331,7 @@ def main():
             "config": {"workload": "bench_vmm: >=64 GiB VA, 1024 x 2 MiB pages per batch, seed-0 shuffled offsets",
                        "mode": args.mode, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
-                       "fanout": "rccl broadcast + all-reduce(min)" if world > 1 else "local"},
+                       "fanout": f"{backend} broadcast + all-reduce(min)" if world > 1 else "local"},
             "p50_map_batch_ms": round(main_sum["p50_map_batch_ms"], 3),
             "p90_map_batch_ms": round(main_sum["p90_map_batch_ms"], 3),
             "us_per_page": round(main_sum["us_per_page"], 3),

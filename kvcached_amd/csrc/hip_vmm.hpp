@@ -13,7 +13,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <iterator>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,13 +66,23 @@ struct VmmCounters {
   std::atomic<int64_t> created{0}, released{0}, reused{0};
 };
 
-// A bounded stack of idle physical allocations of one size on one device. hipMemCreate costs
-// O(live allocations) on ROCm (4 us at 1k live handles, 70 us at 28k) and hipMemRelease ~40 us, so
-// recycling is what keeps the map path flat (~10 us/page). Idle handles hold HBM, so the pool is
-// bounded (KVCACHED_PHYS_POOL_MB, default 4096; trim() empties it) and pressure-aware: when the
-// device's free memory is below the allocator's own headroom (1 - KVCACHED_GPU_UTILIZATION of the
-// total), released handles go straight back to the driver like the reference's GPUPage destructor
-// (csrc/page.cpp:17) and the idle ones are drained.
+// A physical allocation plus the order in which it was created. The order matters on ROCm:
+// hipMemRelease walks a creation-ordered list from its head (3.7 us for the oldest handles, 46 us
+// for the newest, tools/create_diag.cpp) and the hole left at the head makes later hipMemCreate
+// calls O(1) instead of O(live handles). Hence: always release oldest-first.
+struct Phys {
+  phys_handle_t h{};
+  uint64_t seq = 0;
+};
+
+// A bounded set of idle physical allocations of one size on one device. hipMemCreate costs
+// O(live allocations) on ROCm (4 us at 1k live handles, 70-200 us at 20-28k), so recycling is what
+// keeps the map path flat (~10 us/page). Idle handles hold HBM, so the pool is bounded
+// (KVCACHED_PHYS_POOL_MB, default 16384 = 5.5 % of the HBM; trim() empties it) and pressure-aware: when the device's
+// free memory is below the allocator's own headroom (1 - KVCACHED_GPU_UTILIZATION of the total),
+// released handles go straight back to the driver like the reference's GPUPage destructor
+// (csrc/page.cpp:17) and the idle ones are drained (also checked at 10 Hz by the allocator's watcher thread,
+// so an idle engine does not starve a co-located one). Eviction is oldest-created-first.
 class PhysPool {
 public:
   PhysPool(int dev, size_t granule, bool exportable, VmmCounters *ctr)
@@ -81,56 +94,64 @@ public:
   void set_cap_bytes(size_t b) { cap_handles_ = b / granule_; }
 
   // `recycled` tells the caller whether the memory may hold old data.
-  phys_handle_t acquire(bool *recycled) {
+  Phys acquire(bool *recycled) {
     {
       std::lock_guard<std::mutex> g(mu_);
       if (!idle_.empty()) {
-        phys_handle_t h = idle_.back();
-        idle_.pop_back();
+        auto it = std::prev(idle_.end()); // youngest: the old ones stay cheap to give back
+        Phys p{it->second, it->first};
+        idle_.erase(it);
         ctr_->reused++;
         *recycled = true;
-        return h;
+        return p;
       }
     }
-    phys_handle_t h{};
+    Phys p;
     auto prop = make_alloc_prop(dev_, exportable_);
-    HIP_CHECK(hipMemCreate(&h, granule_, &prop, 0));
+    HIP_CHECK(hipMemCreate(&p.h, granule_, &prop, 0));
+    p.seq = next_seq_.fetch_add(1) + 1;
     ctr_->created++;
     *recycled = false;
-    return h;
+    return p;
   }
 
-  void release(phys_handle_t h) {
-    if (!under_pressure()) {
+  void release(Phys p) { release_batch(&p, 1); }
+
+  // Takes handles back. What exceeds the cap (or everything, under memory pressure) goes to the
+  // driver in creation order, oldest first.
+  void release_batch(Phys *ps, size_t n) {
+    if (n == 0) return;
+    std::vector<Phys> victims;
+    const bool pressure = under_pressure();
+    {
       std::lock_guard<std::mutex> g(mu_);
-      if (idle_.size() < cap_handles_) {
-        idle_.push_back(h);
-        return;
+      for (size_t i = 0; i < n; ++i) idle_.emplace(ps[i].seq, ps[i].h);
+      const size_t keep = pressure ? 0 : cap_handles_;
+      while (idle_.size() > keep) {
+        auto it = idle_.begin();
+        victims.push_back(Phys{it->second, it->first});
+        idle_.erase(it);
       }
     }
-    hipError_t st = hipMemRelease(h);
-    if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease failed: %s", hipGetErrorString(st));
-    ctr_->released++;
+    to_driver(victims);
   }
 
-  // Give idle memory back to the driver, keeping at most `keep` handles.
+  // Give idle memory back to the driver, keeping at most `keep` (the youngest) handles.
   void drain(size_t keep) {
-    std::vector<phys_handle_t> victims;
+    std::vector<Phys> victims;
     {
       std::lock_guard<std::mutex> g(mu_);
       while (idle_.size() > keep) {
-        victims.push_back(idle_.back());
-        idle_.pop_back();
+        auto it = idle_.begin();
+        victims.push_back(Phys{it->second, it->first});
+        idle_.erase(it);
       }
     }
-    for (auto h : victims) {
-      hipError_t st = hipMemRelease(h);
-      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease failed: %s", hipGetErrorString(st));
-      ctr_->released++;
-    }
+    to_driver(victims);
   }
-  // hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release.
-  bool under_pressure() {
+
+  // hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release batch.
+  bool under_pressure() const {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
       (void)hipGetLastError();
@@ -140,13 +161,22 @@ public:
       const char *e = std::getenv("KVCACHED_GPU_UTILIZATION");
       return e ? std::atof(e) : 0.95;
     }();
-    const bool low = free_b < static_cast<size_t>(total_b * (1.0 - util));
-    if (low && idle_count() > 0) drain(0);
-    return low;
+    return free_b < static_cast<size_t>(total_b * (1.0 - util));
   }
   size_t idle_count() {
     std::lock_guard<std::mutex> g(mu_);
     return idle_.size();
+  }
+
+  // Release handles that never enter the pool (imports, teardown), oldest first.
+  void to_driver(std::vector<Phys> &v) {
+    std::sort(v.begin(), v.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; });
+    for (auto &p : v) {
+      hipError_t st = hipMemRelease(p.h);
+      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease failed: %s", hipGetErrorString(st));
+      ctr_->released++;
+    }
+    (void)hipGetLastError();
   }
 
 private:
@@ -155,8 +185,9 @@ private:
   bool exportable_;
   VmmCounters *ctr_;
   size_t cap_handles_ = 0;
+  std::atomic<uint64_t> next_seq_{0};
   std::mutex mu_;
-  std::vector<phys_handle_t> idle_;
+  std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle
 };
 
 inline void *vmm_reserve(size_t size, size_t align, void *hint) {

@@ -97,25 +97,47 @@ struct CompactArgs {
   int64_t src[kMaxMovesPerLaunch];
   int64_t dst[kMaxMovesPerLaunch];
 };
-static_assert(sizeof(CompactArgs) <= 3072, "kernarg segment budget");
+static_assert(sizeof(CompactArgs) <= 8192, "kernarg segment budget");
 
 static constexpr int kCompactThreads = 256;          // 4 waves
 static constexpr int kCompactTile = 16 * 1024;       // bytes per workgroup: 4 waves x 4 x 1 KiB
 static constexpr int kPiece = 1024;                  // one wave-instruction
 static constexpr int kPiecesPerWave = kCompactTile / kPiece / (kCompactThreads / 64);
 
+// blockIdx -> (region, move, tile). XCD == true: the (region, move) pairs are dealt to the 8 XCDs so that one
+// XCD copies a whole block (all its tiles) — the same placement idea as zero_fill_pages; speed only.
+template <bool XCD>
+__device__ __forceinline__ bool compact_index(unsigned n_moves, unsigned n_regions, unsigned tiles_per_block, unsigned &r,
+                                              unsigned &m, unsigned &t) {
+  if (XCD) {
+    const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const unsigned q = i / tiles_per_block;
+    t = i - q * tiles_per_block;
+    const unsigned pair = q * 8u + x;
+    if (pair >= n_moves * n_regions) return false;
+    r = pair / n_moves;
+    m = pair - r * n_moves;
+  } else {
+    t = blockIdx.x % tiles_per_block;
+    m = (blockIdx.x / tiles_per_block) % n_moves;
+    r = blockIdx.x / (tiles_per_block * n_moves);
+  }
+  return true;
+}
+
 // Variant 0 — LDS-staged. Each wave DMAs its four 1 KiB pieces global->LDS
 // (global_load_lds_dwordx4: per-lane source address, wave-uniform LDS base + lane*16), waits
 // for its own DMAs (vmcnt), reads them back with ds_read_b128 and streams them out with
 // global_store_dwordx4. A wave only ever reads LDS bytes it loaded itself, so no barrier is
 // needed; 16 KiB of LDS per workgroup lets 8+ workgroups share a CU (>=128 KiB in flight).
+template <bool XCD>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(CompactArgs a, unsigned n_moves,
+                                                                              unsigned n_regions,
                                                                               unsigned tiles_per_block,
                                                                               unsigned block_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[kCompactTile];
-  const unsigned t = blockIdx.x % tiles_per_block;
-  const unsigned m = (blockIdx.x / tiles_per_block) % n_moves;
-  const unsigned r = blockIdx.x / (tiles_per_block * n_moves);
+  unsigned r, m, t;
+  if (!compact_index<XCD>(n_moves, n_regions, tiles_per_block, r, m, t)) return;
   const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
   char *dst = static_cast<char *>(a.base[r]) + a.dst[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
   const unsigned remain = block_bytes - t * kCompactTile; // bytes of this tile that exist (>= 16)
@@ -150,12 +172,13 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(Com
 }
 
 // Variant 1 — register-staged: all loads of a lane in flight first, then the stores.
+template <bool XCD>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(CompactArgs a, unsigned n_moves,
+                                                                              unsigned n_regions,
                                                                               unsigned tiles_per_block,
                                                                               unsigned block_bytes) {
-  const unsigned t = blockIdx.x % tiles_per_block;
-  const unsigned m = (blockIdx.x / tiles_per_block) % n_moves;
-  const unsigned r = blockIdx.x / (tiles_per_block * n_moves);
+  unsigned r, m, t;
+  if (!compact_index<XCD>(n_moves, n_regions, tiles_per_block, r, m, t)) return;
   const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
   char *dst = static_cast<char *>(a.base[r]) + a.dst[m] * (int64_t)block_bytes + (size_t)t * kCompactTile;
   const unsigned remain = block_bytes - t * kCompactTile;
@@ -193,14 +216,24 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
     a.dst[i] = dst[i];
   }
   const unsigned tiles = (unsigned)((block_bytes + kCompactTile - 1) / kCompactTile);
-  const size_t grid = (size_t)tiles * (size_t)n_moves * (size_t)n_regions;
-  if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-  if (variant == 1)
-    compact_blocks_reg_kernel<<<dim3((unsigned)grid), dim3(kCompactThreads), 0, stream>>>(a, (unsigned)n_moves, tiles,
-                                                                                         (unsigned)block_bytes);
-  else
-    compact_blocks_lds_kernel<<<dim3((unsigned)grid), dim3(kCompactThreads), 0, stream>>>(a, (unsigned)n_moves, tiles,
-                                                                                         (unsigned)block_bytes);
+  const size_t pairs = (size_t)n_moves * (size_t)n_regions;
+  const size_t grid = (size_t)tiles * pairs, grid_xcd = (size_t)tiles * ((pairs + 7) / 8 * 8);
+  if (grid_xcd > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 blk(kCompactThreads);
+  const unsigned nm = (unsigned)n_moves, nr = (unsigned)n_regions, bb = (unsigned)block_bytes;
+  switch (variant) {
+  case 1: // register-staged, XCD-aware
+    compact_blocks_reg_kernel<true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+    break;
+  case 2: // LDS-staged, interleaved (pre-XCD-aware mapping, for A/B runs)
+    compact_blocks_lds_kernel<false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+    break;
+  case 3: // register-staged, interleaved
+    compact_blocks_reg_kernel<false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+    break;
+  default: // LDS-staged, XCD-aware
+    compact_blocks_lds_kernel<true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+  }
   return hipGetLastError();
 }
 

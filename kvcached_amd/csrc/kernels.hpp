@@ -13,7 +13,7 @@ static constexpr size_t kFillSlabBytes = 64 * 1024;
 // Pointers (pages / regions) and moves one launch carries in its kernarg segment.
 static constexpr int kMaxPtrsPerLaunch = 256;
 static constexpr int kMaxRegionsPerLaunch = 128;
-static constexpr int kMaxMovesPerLaunch = 120;
+static constexpr int kMaxMovesPerLaunch = 448; // 448 x 16 B + 128 x 8 B = 8 KiB of kernarg
 
 // Zero `n` pages of `page_bytes` each (n <= kMaxPtrsPerLaunch). Asynchronous on `stream`.
 // variant: 0 = default; others are tuning variants kept for A/B runs.
@@ -22,7 +22,8 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
 // Copy blocks inside each region: for r < n_regions, m < n_moves:
 //   bases[r] + dst[m]*block_bytes  <-  bases[r] + src[m]*block_bytes
 // n_regions <= kMaxRegionsPerLaunch, n_moves <= kMaxMovesPerLaunch. variant 0 = LDS-staged
-// (LDS-DMA in, ds_read_b128 + global_store out), 1 = register-staged.
+// (LDS-DMA in, ds_read_b128 + global_store out) with XCD-aware block placement, 1 = register-staged
+// XCD-aware, 2/3 = the same two with the plain interleaved placement (A/B runs).
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant = 0);
 

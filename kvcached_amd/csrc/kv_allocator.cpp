@@ -110,6 +110,19 @@ void GpuContext::drain_pools() {
   for (auto *p : ps) p->drain(0);
 }
 
+void GpuContext::relieve_pressure() {
+  std::vector<PhysPool *> ps;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto &m : pools_)
+      for (auto &kv : m) ps.push_back(kv.second.get());
+  }
+  if (ps.empty()) return;
+  (void)hipSetDevice(dev_);
+  if (ps[0]->under_pressure())
+    for (auto *p : ps) p->drain(0);
+}
+
 void GpuContext::begin_timed(hipStream_t s, int kind) {
   if (!options().profile.load()) return;
   std::lock_guard<std::mutex> g(mu_);
@@ -216,7 +229,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   // KVCACHED_ZERO_BACKFILL=true for the reference's "stray reads return zeros" semantics.
   options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", false) ? 1 : 0;
   options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
-  options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 4096) << 20;
+  options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 16384) << 20;
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
@@ -327,6 +340,7 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
     r->base = static_cast<char *>(p);
   }
   r->handle.assign(r->num_slots(), phys_handle_t{});
+  r->seq.assign(r->num_slots(), 0);
   r->mapped.assign(r->num_slots(), 0);
   return r;
 }
@@ -385,16 +399,21 @@ void KvAllocator::destroy_region(KvRegion &r) {
     whole = st == hipSuccess;
     if (!whole) KVC_LOG(LOG_ERROR, "hipMemUnmap of whole region %s failed: %s", r.name.c_str(), hipGetErrorString(st));
   }
+  std::vector<Phys> dead;
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.mapped[i]) continue;
     if (!whole) {
       hipError_t st = hipMemUnmap(r.base + i * r.page_size, r.page_size);
       if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemUnmap during cleanup failed: %s", hipGetErrorString(st));
     }
-    hipError_t st = hipMemRelease(r.handle[i]);
+    dead.push_back(Phys{r.handle[i], r.seq[i]});
+    r.mapped[i] = 0;
+  }
+  std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
+  for (auto &p : dead) {
+    hipError_t st = hipMemRelease(p.h);
     if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease during cleanup failed: %s", hipGetErrorString(st));
     stats().vmm.released++;
-    r.mapped[i] = 0;
   }
   if (r.backfilled && !whole) // aliases that could not be dropped in one call
     for (size_t i = 0; i < r.num_slots(); ++i) (void)hipMemUnmap(r.base + i * r.page_size, r.page_size);
@@ -607,7 +626,8 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (r.backfilled) HIP_CHECK(hipMemUnmap(va, ps));
       int64_t t1 = now_ns();
       bool recycled = false;
-      phys_handle_t h = imported ? (*imported)[next_import++] : pool->acquire(&recycled);
+      Phys ph = imported ? Phys{(*imported)[next_import++], 0} : pool->acquire(&recycled);
+      phys_handle_t h = ph.h;
       int64_t t2 = now_ns();
       hipError_t st = hipMemMap(va, ps, 0, h, 0);
       int64_t t3 = now_ns();
@@ -615,11 +635,12 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       stats().t_acquire += t2 - t1;
       stats().t_map += t3 - t2;
       if (st != hipSuccess) {
-        if (!imported) pool->release(h);
+        if (!imported) pool->release(ph);
         if (r.backfilled && hipMemMap(va, ps, 0, r.zero_of(s.index), 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
         HIP_CHECK(st);
       }
       r.handle[s.index] = h;
+      r.seq[s.index] = ph.seq;
       r.mapped[s.index] = imported ? 2 : 1;
       done.push_back(s);
       if (!(run_len && va == run_start + run_len && run_len < kMaxRunBytes)) {
@@ -643,7 +664,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       char *va = r.base + it->index * ps;
       (void)hipMemUnmap(va, ps);
       if (r.mapped[it->index] == 1)
-        pool->release(r.handle[it->index]);
+        pool->release(Phys{r.handle[it->index], r.seq[it->index]});
       else
         (void)hipMemRelease(r.handle[it->index]);
       r.mapped[it->index] = 0;
@@ -686,6 +707,8 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     run_len = 0;
   };
   int64_t n_done = 0;
+  std::vector<Phys> freed; // returned to the pool / driver in one batch, oldest first
+  freed.reserve(slots.size());
   for (auto &s : slots) {
     KvRegion &r = *s.region;
     if (!r.mapped[s.index]) { // reference: log + skip (ftensor.cpp:124-127)
@@ -698,8 +721,7 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     const int64_t t1 = now_ns();
     stats().t_unmap += t1 - t0;
     if (r.mapped[s.index] == 1) {
-      pool->release(r.handle[s.index]);
-      stats().t_release += now_ns() - t1;
+      freed.push_back(Phys{r.handle[s.index], r.seq[s.index]});
     } else {
       hipError_t st = hipMemRelease(r.handle[s.index]);
       if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
@@ -718,8 +740,12 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
   }
   flush_run();
-  // stale entries would keep pointing at physical pages that now belong to the pool or to the driver
+  // stale entries would keep pointing at physical pages that now belong to the pool or to the driver:
+  // invalidate BEFORE the handles can be recycled or freed
   if (n_done) ctx->tlb_shootdown();
+  const int64_t tr0 = now_ns();
+  pool->release_batch(freed.data(), freed.size());
+  stats().t_release += now_ns() - tr0;
   stats().pages_unmapped += n_done;
 }
 

@@ -23,7 +23,7 @@ namespace kvc {
 struct Options {
   std::atomic<int64_t> zero_backfill{0};
   std::atomic<int64_t> zero_fill{1};
-  std::atomic<int64_t> pool_bytes{4096ll << 20};
+  std::atomic<int64_t> pool_bytes{16384ll << 20};
   std::atomic<int64_t> profile{0};
   std::atomic<int64_t> tlb_shootdown{1};
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
@@ -58,6 +58,7 @@ public:
   hipStream_t stream() const { return stream_; }
   PhysPool *pool(size_t granule, bool exportable);
   void drain_pools();
+  void relieve_pressure(); // drain idle handles if the device is short of free memory (10 Hz from the watcher)
 
   // kernel launches on `s` (NULL = own stream), timed with events when profiling is on
   void zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s);
@@ -97,6 +98,7 @@ struct KvRegion {
   size_t fanout = 1;
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
+  std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page
   size_t num_slots() const { return size / page_size; }
 };

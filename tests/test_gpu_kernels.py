@@ -94,14 +94,14 @@ def _oracle_compact(lib, hosts, src, dst, block_bytes):
     lib.okvc_compact_blocks(bases, len(hosts), T._arr(src), T._arr(dst), len(src), block_bytes)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("block_bytes,n_blocks,n_regions,n_moves,seed", [
     (32 * KiB, 256, 4, 40, 0),       # Llama-3-8B block (16 tok x 2048 B): two full 16 KiB tiles
     (16 * KiB, 128, 3, 7, 1),        # cfg-1 block: exactly one tile
     (48 * KiB, 64, 2, 9, 2),         # three tiles
     (18432, 113, 2, 30, 3),          # MLA block 16 x 1152 B: one full tile + ragged 2 KiB tail
     (16, 1000, 1, 100, 4),           # minimum block: one lane
-    (1040, 500, 5, 121, 5),          # ragged inside the first piece; more moves than one launch (120)
+    (1040, 1000, 5, 449, 5),         # ragged inside the first piece; more moves than one launch (448)
     (32 * KiB, 64, 130, 3, 6),       # more regions than one launch (128)
     (32 * KiB, 64, 2, 0, 7),         # empty move list
 ])
