@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — GB/s of KV physically backed (map + zero) at 2 MiB granularity on MI355X.
 
-Workload (BASELINE.json configs[1], "bench_vmm"): reserve >= 64 GiB of VA, back it in batches of
-1024 x 2 MiB pages. One STEP = one call of the batched hot path on one batch:
-kvc_map_to_kv_tensors(1024 offsets) = pooled/created physical handles + hipMemMap + ranged
-hipMemSetAccess + the zero_fill_pages kernel, returning after the fill completed. Offsets inside
-a batch are a seed-0 permutation. Unmapping happens after the timed region and is
-reported separately (`unmap_GBps`).
+Workload (BASELINE.json configs[1], "bench_vmm: reserve 64 GiB VA, map/unmap 2 MiB pages in 1024-page
+batches"): one STEP = one elastic cycle on one batch of 1024 x 2 MiB pages, sweeping the 64 GiB window:
+  kvc_map_to_kv_tensors(1024 offsets)   pooled/created handles + hipMemMap + hipMemSetAccess + TLB
+                                        shootdown + the zero_fill_pages kernel; returns after the fill
+  kvc_unmap_from_kv_tensors(same)       hipMemUnmap + TLB shootdown + handles back to the pool/driver
+Both halves are inside the timed bracket; `value` = bytes backed / total wall time. `map_zero_GBps` and
+`p50_map_batch_ms` isolate the map+zero half. Offsets inside a batch are a seeded permutation (SURVEY
+§8d). The other natural reading — a growth burst of K batches with nothing unmapped — is reported as the
+variant `growth_burst` (there hipMemCreate's O(live handles) cost dominates).
 
   python bench.py [--gpus N --steps K --warmup W]
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the path shards with no
@@ -101,7 +104,10 @@ def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
     return per
 
 
-def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0):
+def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0,
+            burst=False):
+    """cycle (default): every step maps+zeroes one batch and unmaps it again. burst=True: `steps` batches are
+    backed one after the other and only unmapped after the timed region."""
     window = max(32, steps + warmup)  # >= 64 GiB of VA
     pool = Pool(capi, device, window, mode, pool_mb, compound_layers=compound_layers)
     slot = pool.slot
@@ -111,19 +117,28 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
             unmapper = lambda offs: fanout.unmap_from_kv_tensors(offs)  # noqa: E731
         else:
             mapper, unmapper = capi.map_to_kv_tensors, capi.unmap_from_kv_tensors
-        # warm-up: back W batches and give them back, so that code paths are warm and the idle-handle
-        # pool holds what its cap allows (the steady state of an elastic pool)
-        run_steps(capi, mapper, 0, warmup, slot)
+        # warm-up: W full cycles (code paths warm, the idle-handle pool holds what its cap allows)
         for b in range(warmup):
-            unmapper(batch_offsets(b, slot=slot))
+            offs = batch_offsets(b % window, slot=slot)
+            mapper(offs)
+            unmapper(offs)
         capi.set_option(capi.OPT_PROFILE, 1)
         capi.reset_stats()
         if barrier:
             barrier()
         if sync:
             sync()
+        per_map, per_unmap = [], []
         t0 = time.perf_counter()
-        per = run_steps(capi, mapper, warmup, steps, slot)
+        for i in range(steps):
+            offs = batch_offsets((warmup + i) % window, slot=slot)
+            ta = time.perf_counter()
+            mapper(offs)
+            tb = time.perf_counter()
+            per_map.append(tb - ta)
+            if not burst:
+                unmapper(offs)
+                per_unmap.append(time.perf_counter() - tb)
         if sync:
             sync()
         if barrier:
@@ -132,13 +147,13 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         st = capi.get_stats()
         st["driver_ns"] = capi.get_driver_breakdown()
         capi.set_option(capi.OPT_PROFILE, 0)
-        # give everything back (untimed for the headline, reported on its own)
-        t1 = time.perf_counter()
-        for b in range(warmup, warmup + steps):
-            unmapper(batch_offsets(b, slot=slot))
-        unmap_s = time.perf_counter() - t1
-        return {"elapsed": elapsed, "per_step": per, "stats": st, "unmap_s": unmap_s, "reserve_s": pool.reserve_s,
-                "window_GiB": pool.size / GiB}
+        if burst:  # give everything back, outside the timed region
+            for i in range(steps):
+                tb = time.perf_counter()
+                unmapper(batch_offsets((warmup + i) % window, slot=slot))
+                per_unmap.append(time.perf_counter() - tb)
+        return {"elapsed": elapsed, "per_step": per_map, "per_unmap": per_unmap, "stats": st, "reserve_s": pool.reserve_s,
+                "window_GiB": pool.size / GiB, "burst": burst}
     finally:
         pool.close()
 
@@ -146,13 +161,16 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
 def summarize(res, steps, n_gpus=1):
     bytes_per_step = BATCH_PAGES * PAGE
     st = res["stats"]
+    t_map, t_unmap = sum(res["per_step"]), sum(res["per_unmap"])
     out = {
         "GBps": n_gpus * steps * bytes_per_step / res["elapsed"] / 1e9,
         "ms_per_step": res["elapsed"] / steps * 1e3,
+        "map_zero_GBps": n_gpus * steps * bytes_per_step / t_map / 1e9,
         "p50_map_batch_ms": statistics.median(res["per_step"]) * 1e3,
         "p90_map_batch_ms": sorted(res["per_step"])[int(0.9 * (len(res["per_step"]) - 1))] * 1e3,
-        "us_per_page": res["elapsed"] / steps / BATCH_PAGES * 1e6,
-        "unmap_GBps": (len(res["per_step"]) + 0) * bytes_per_step / max(res["unmap_s"], 1e-9) / 1e9,
+        "map_us_per_page": t_map / steps / BATCH_PAGES * 1e6,
+        "unmap_us_per_page": t_unmap / max(1, len(res["per_unmap"])) / BATCH_PAGES * 1e6,
+        "unmap_GBps": len(res["per_unmap"]) * bytes_per_step / max(t_unmap, 1e-9) / 1e9,
         "handles_created": st["handles_created"], "handles_reused": st["handles_reused"],
         "va_reserve_and_backfill_s": res["reserve_s"],
         "driver_us_per_page": {k: round(v / 1e3 / (steps * BATCH_PAGES), 2) for k, v in st.get("driver_ns", {}).items() if v},
@@ -216,42 +234,42 @@ def cpu_baseline():
 
 REF_SNIPPET = r"""
 import importlib.machinery, importlib.util, json, sys, time, torch
-so, steps, warmup = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+so, steps, warmup, burst = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "burst"
 loader = importlib.machinery.ExtensionFileLoader("vmm_ops", so)
 spec = importlib.util.spec_from_loader("vmm_ops", loader)
 ref = importlib.util.module_from_spec(spec); loader.exec_module(ref)
 PAGE, N = 2 << 20, 1024
 import numpy as np
 window = max(32, steps + warmup)
-offs = lambda b: [int(b * N + p) * PAGE for p in np.random.default_rng(b).permutation(N)]
+offs = lambda b: [int((b % window) * N + p) * PAGE for p in np.random.default_rng(b % window).permutation(N)]
 ref.init_kvcached("cuda:0", PAGE, False)
 t0 = time.perf_counter()
 ref.create_kv_tensors(window * N * PAGE, 1, "cuda:0", 1, 1, 0, True)
 t_create = time.perf_counter() - t0
 for b in range(warmup):
-    assert ref.map_to_kv_tensors(offs(b))
-for b in range(warmup):
-    assert ref.unmap_from_kv_tensors(offs(b))
+    assert ref.map_to_kv_tensors(offs(b)); assert ref.unmap_from_kv_tensors(offs(b))
 torch.cuda.synchronize()
-per = []
+pm, pu = [], []
 t_all = time.perf_counter()
-for b in range(warmup, warmup + steps):
-    t0 = time.perf_counter(); assert ref.map_to_kv_tensors(offs(b)); per.append(time.perf_counter() - t0)
+for i in range(steps):
+    o = offs(warmup + i)
+    ta = time.perf_counter(); assert ref.map_to_kv_tensors(o); tb = time.perf_counter(); pm.append(tb - ta)
+    if not burst:
+        assert ref.unmap_from_kv_tensors(o); pu.append(time.perf_counter() - tb)
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t_all
-tu = time.perf_counter()
-for b in range(warmup, warmup + steps):
-    assert ref.unmap_from_kv_tensors(offs(b))
-tu = time.perf_counter() - tu
-print(json.dumps({"GBps": steps * N * PAGE / t_all / 1e9, "p50_map_batch_ms": sorted(per)[len(per)//2] * 1e3,
-                  "first_batch_ms": per[0] * 1e3, "last_batch_ms": per[-1] * 1e3,
-                  "us_per_page": t_all / steps / N * 1e6, "unmap_GBps": steps * N * PAGE / tu / 1e9,
-                  "va_reserve_and_backfill_s": t_create, "steps": steps, "warmup": warmup, "window_GiB": window * 2}))
+if burst:
+    for i in range(steps):
+        tb = time.perf_counter(); assert ref.unmap_from_kv_tensors(offs(warmup + i)); pu.append(time.perf_counter() - tb)
+print(json.dumps({"GBps": steps * N * PAGE / t_all / 1e9, "map_GBps": steps * N * PAGE / sum(pm) / 1e9,
+                  "p50_map_batch_ms": sorted(pm)[len(pm)//2] * 1e3, "map_us_per_page": sum(pm) / steps / N * 1e6,
+                  "unmap_us_per_page": sum(pu) / steps / N * 1e6, "va_reserve_and_backfill_s": t_create,
+                  "steps": steps, "warmup": warmup, "window_GiB": window * 2, "workload": "burst" if burst else "cycle"}))
 ref.shutdown_kvcached()
 """
 
 
-def reference_on_box(steps, warmup):
+def reference_on_box(steps, warmup, burst=False):
     """The REAL reference (oracle/_ref/vmm_ops.so, compiled from its own sources in the build
     container) running its own HIP path on this GPU on the SAME workload (same window, warm-up, steps and
     offsets): its FTensor::map per page = unmap zero alias + hipMemCreate + hipMemMap + hipMemSetAccess,
@@ -261,8 +279,8 @@ def reference_on_box(steps, warmup):
     if not os.path.exists(so):
         return None
     try:
-        out = subprocess.run([sys.executable, "-c", REF_SNIPPET, so, str(steps), str(warmup)], capture_output=True,
-                             text=True, timeout=600)
+        out = subprocess.run([sys.executable, "-c", REF_SNIPPET, so, str(steps), str(warmup), "burst" if burst else "cycle"],
+                             capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:]}
@@ -328,13 +346,16 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "bench_vmm: >=64 GiB VA, 1024 x 2 MiB pages per batch, seed-0 shuffled offsets",
+            "config": {"workload": "bench_vmm: 64 GiB VA window; step = map+zero then unmap one batch of 1024 x 2 MiB "
+                                   "pages (shuffled offsets), both halves timed",
                        "mode": args.mode, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if world > 1 else "local"},
+            "map_zero_GBps": round(main_sum["map_zero_GBps"], 2),
             "p50_map_batch_ms": round(main_sum["p50_map_batch_ms"], 3),
             "p90_map_batch_ms": round(main_sum["p90_map_batch_ms"], 3),
-            "us_per_page": round(main_sum["us_per_page"], 3),
+            "map_us_per_page": round(main_sum["map_us_per_page"], 3),
+            "unmap_us_per_page": round(main_sum["unmap_us_per_page"], 3),
             "unmap_GBps": round(main_sum["unmap_GBps"], 2),
             "handles_created": main_sum["handles_created"], "handles_reused": main_sum["handles_reused"],
             "va_reserve_and_backfill_s": round(main_sum["va_reserve_and_backfill_s"], 3),
@@ -344,19 +365,19 @@ def main():
         if world == 1:
             if not args.no_variants:
                 variants = {}
-                for name, mode, pool, comp in (("lazy_pool_64GiB_all_recycled", "lazy", 65536, 0),
-                                               ("lazy_no_pool_all_created", "lazy", 0, 0),
-                                               ("compat_sharded_zero_pages", "compat", None, 0),
-                                               ("compat_pool_64GiB_all_recycled", "compat", 65536, 0),
-                                               ("lazy_contiguous_layout_128MiB_compound_pages", "lazy", None, 32)):
+                for name, mode, pool, comp, burst in (
+                        ("growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True),
+                        ("no_pool_every_handle_created_and_released", "lazy", 0, 0, False),
+                        ("compat_zero_backfill_sharded", "compat", None, 0, False),
+                        ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False)):
                     try:
-                        # warm-up backs and releases as many batches as are timed: a large pool then serves
-                        # every timed batch from recycled handles (the steady state of an elastic pool)
-                        r1 = measure(capi, device, 8, 8, mode, pool, compound_layers=comp)
-                        s = summarize(r1, 8)
+                        nsteps = 24 if burst else 8
+                        r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst)
+                        s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
-                                          for k in ("GBps", "p50_map_batch_ms", "us_per_page", "unmap_GBps",
-                                                    "handles_created", "handles_reused", "driver_us_per_page")}
+                                          for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",
+                                                    "unmap_us_per_page", "handles_created", "handles_reused",
+                                                    "driver_us_per_page")}
                         rf = roofline_from(r1["stats"])
                         variants[name]["fill_GBps"] = rf["achieved"] if rf else None
                     except Exception as e:
@@ -365,6 +386,7 @@ def main():
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
                 line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)
+                line["reference_hip_path_growth_burst"] = reference_on_box(24, 4, burst=True)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Copy the newest rocprofv3 outputs of gpurun_out/ into profiles/ (tracked) and derive
+profiles/zero_fill_traffic.json (read by bench.py for roofline.traffic)."""
+import csv, glob, json, os, shutil, statistics, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+def newest(pattern):
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return f[-1] if f else None
+os.makedirs("profiles", exist_ok=True)
+ks, kt = newest("gpurun_out/prof_kt/runc/*_kernel_stats.csv"), newest("gpurun_out/prof_kt/runc/*_kernel_trace.csv")
+shutil.copy(ks, f"profiles/{R}_rocprofv3_kernel_stats.csv")
+shutil.copy(newest("gpurun_out/prof_kt/runc/*_domain_stats.csv"), f"profiles/{R}_rocprofv3_domain_stats.csv")
+rows = list(csv.DictReader(open(kt)))
+big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] == "4194304"]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in big]
+w = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_w/runc/*_counter_collection.csv"))))
+rd = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_r/runc/*_counter_collection.csv"))))
+ws = [float(x["Counter_Value"]) for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] == "4194304"]
+fs = [float(x["Counter_Value"]) for x in rd if x["Counter_Name"] == "FETCH_SIZE" and x["Grid_Size"] == "4194304"]
+bench = json.loads(open("gpurun_out/bench.log").read().strip().splitlines()[-1])
+json.dump(bench, open(f"profiles/{R}_bench_n1.json", "w"))
+out = {"kernel": "kvc::zero_fill_pages_kernel<512,false,true>",
+       "launch_shape": "256 pages x 2 MiB = 8192 workgroups x 512 threads (grid 4194304)",
+       "algorithmic_bytes_per_launch": 536870912,
+       "rocprofv3_kernel_trace": {"launches": len(d), "avg_us": round(sum(d) / len(d), 2), "median_us": round(statistics.median(d), 2),
+                                  "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(536870912 / (sum(d) / len(d)) / 1e3, 1)},
+       "bench_hip_events": {"avg_launch_us": bench["roofline"]["avg_launch_us"], "achieved_GBps": bench["roofline"]["achieved"]},
+       "pmc": {"WRITE_SIZE_KiB_per_launch": statistics.mean(ws), "FETCH_SIZE_KiB_per_launch_raw": round(statistics.mean(fs), 2),
+               "note": "separate --pmc passes; WRITE_SIZE exact for 16 B/lane streaming stores; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B), MI355X_MICROARCH.md"},
+       "write_bytes_per_launch": int(statistics.mean(ws) * 1024), "read_bytes_per_launch": int(2 * statistics.mean(fs) * 1024)}
+out["hbm_bytes_per_launch"] = out["write_bytes_per_launch"] + out["read_bytes_per_launch"]
+json.dump(out, open("profiles/zero_fill_traffic.json", "w"), indent=1)
+for src, dst in (("bench_elastic.log", f"{R}_bench_elastic.jsonl"), ("bench_tp_ipc.log", f"{R}_bench_tp_ipc.jsonl"),
+                 ("create_diag.log", f"{R}_create_release_order.log"), ("compact_bench3.log", f"{R}_compact_bench.jsonl"),
+                 ("bench_n2_rehearsal.log", f"{R}_bench_n2_gloo_rehearsal.log"), ("pytest_gpu.log", f"{R}_pytest_gpu.log")):
+    if os.path.exists("gpurun_out/" + src):
+        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
+print(open(f"profiles/{R}_rocprofv3_kernel_stats.csv").read())
+print(json.dumps(out["rocprofv3_kernel_trace"]), json.dumps(out["bench_hip_events"]))

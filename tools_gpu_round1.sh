@@ -26,3 +26,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo "== rocprofv3 PMC FETCH_SIZE (own pass)"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof_pmc_r -- python3 bench.py --no-variants --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/prof_pmc_r.log 2>&1; echo "pmc fetch rc=$?"
 find gpurun_out/prof_kt gpurun_out/prof_pmc_w gpurun_out/prof_pmc_r -name "*.csv" | head -20
+echo "== elastic (config 3)"
+timeout -k 10 600 python benchmarks/bench_elastic.py 2>&1 | grep -v "amdgpu.ids\|IPC listener" > gpurun_out/bench_elastic.log; cut -c1-700 gpurun_out/bench_elastic.log
+echo "== tp ipc (config 4)"
+timeout -k 10 300 python benchmarks/bench_tp_ipc.py 2>&1 | grep -v "amdgpu.ids\|IPC listener" > gpurun_out/bench_tp_ipc.log; cut -c1-400 gpurun_out/bench_tp_ipc.log
