@@ -198,6 +198,38 @@ def roofline_from(st):
             "avg_launch_us": round(ms / launches * 1e3, 2)}
 
 
+def compaction_roofline(capi, device):
+    """Secondary kernel: compact_blocks on the Llama-3-8B geometry (64 regions = 32 layers x K/V, 32 KiB blocks,
+    2048 disjoint moves = 4 GiB read + 4 GiB written). Event-timed like zero_fill_pages."""
+    import numpy as np
+    import torch
+    block, regions, n_blocks, moves = 32 * 1024, 64, 4096, 2048
+    capi.init(device, PAGE, False)
+    try:
+        bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device=device) for _ in range(regions)]
+        ids = np.random.default_rng(0).permutation(n_blocks)[:2 * moves]
+        src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
+        bases = [b.data_ptr() for b in bufs]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            capi.compact_blocks(bases, src, dst, block)
+        capi.set_option(capi.OPT_PROFILE, 1)
+        capi.reset_stats()
+        for _ in range(5):
+            capi.compact_blocks(bases, src, dst, block, sync=False)
+        capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
+        st = capi.get_stats()
+        capi.set_option(capi.OPT_PROFILE, 0)
+        achieved = st["compact_bytes"] / (st["compact_ms"] * 1e-3) / 1e9
+        return {"kernel": "compact_blocks (LDS-staged, XCD-aware)", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
+                "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],
+                "avg_launch_us": round(st["compact_ms"] / st["compact_launches"] * 1e3, 2)}
+    finally:
+        capi.shutdown()
+
+
 def cpu_baseline():
     """The reference's CPU path restated (oracle/, kind "port"), 1 thread, bounded sample: for each
     batch the page-id bookkeeping of the reference allocator (PageAllocator state machine ->
@@ -383,6 +415,10 @@ def main():
                     except Exception as e:
                         variants[name] = {"error": str(e)[:200]}
                 line["variants"] = variants
+                try:
+                    line["roofline_compact_blocks"] = compaction_roofline(capi, device)
+                except Exception as e:
+                    line["roofline_compact_blocks"] = {"error": str(e)[:200]}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
                 line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)

@@ -207,18 +207,29 @@ public:
   int64_t get_page_id(int64_t block_id, int64_t block_mem_size) const {
     return kvc_pa_get_page_id(pa_, block_id, block_mem_size);
   }
-  py::dict group_indices_by_page(const std::vector<int64_t> &indices, int64_t block_mem_size) const {
+  // Takes the Python list as it is (no std::vector round trip) and builds the result with the raw
+  // CPython API: this call sits on every KVCacheManager.free().
+  py::dict group_indices_by_page(py::list indices, int64_t block_mem_size) const {
     const size_t n = indices.size();
-    std::vector<int64_t> keys(n ? n : 1), counts(n ? n : 1), values(n ? n : 1);
-    int64_t k = kvc_pa_group_indices_by_page(pa_, indices.data(), n, block_mem_size, keys.data(), counts.data(),
-                                             values.data());
+    std::vector<int64_t> in(n ? n : 1), keys(n ? n : 1), counts(n ? n : 1), values(n ? n : 1);
+    for (size_t i = 0; i < n; ++i) {
+      const long long v = PyLong_AsLongLong(PyList_GET_ITEM(indices.ptr(), (Py_ssize_t)i));
+      if (v == -1 && PyErr_Occurred()) throw py::error_already_set();
+      in[i] = v;
+    }
+    int64_t k = kvc_pa_group_indices_by_page(pa_, in.data(), n, block_mem_size, keys.data(), counts.data(), values.data());
     if (k < 0) raise_last((int)k);
     py::dict d; // built in the C++ map's iteration order, like pybind11's stl caster does for the reference
     size_t w = 0;
     for (int64_t i = 0; i < k; ++i) {
-      py::list l((size_t)counts[i]);
-      for (int64_t j = 0; j < counts[i]; ++j) l[(size_t)j] = py::int_(values[w++]);
-      d[py::int_(keys[i])] = std::move(l);
+      PyObject *l = PyList_New((Py_ssize_t)counts[i]);
+      if (!l) throw py::error_already_set();
+      for (int64_t j = 0; j < counts[i]; ++j) PyList_SET_ITEM(l, (Py_ssize_t)j, PyLong_FromLongLong(values[w++]));
+      PyObject *key = PyLong_FromLongLong(keys[i]);
+      const int rc = PyDict_SetItem(d.ptr(), key, l);
+      Py_DECREF(key);
+      Py_DECREF(l);
+      if (rc != 0) throw py::error_already_set();
     }
     return d;
   }

@@ -216,3 +216,75 @@ def test_export_import_same_process(vmm):
     assert bool((b[0][epp:epp + 16] == 4321).all())
     assert ops.unmap_from_kv_tensors([PAGE], 1)
     assert ops.unmap_from_kv_tensors([PAGE], 0)
+
+
+# ------------------------------------------------------------------ shared pool across processes
+def _peer_process(sock_path, ipc, q):
+    """The 'peer TP rank': owns its own VA reservation, receives fds over the Unix socket and maps them."""
+    try:
+        os.environ.update(KVCACHED_IPC_NAME=ipc, KVCACHED_LOG_LEVEL="ERROR")
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch
+        torch.cuda.set_device(0)
+        from kvcached_amd import vmm_ops
+        from kvcached_amd import tp_ipc_util as tp
+        vmm_ops.init_kvcached(DEV, PAGE, False)
+        ts = vmm_ops.create_kv_tensors(16 * MiB, 2, DEV, 2, 2, 0, False)
+        srv = tp.start_worker_listener_thread(1)
+        q.put("ready")
+        assert q.get(timeout=120) == "mapped"          # rank 0 has shared its slots with us
+        epp = PAGE // 2
+        vals = [int(t[half + epp + 7]) for t in ts for half in (0, t.numel() // 2)]
+        ts[1][epp + 9] = 777                             # write back through the shared page
+        torch.cuda.synchronize()
+        q.put(("peer_sees", vals))
+        assert q.get(timeout=120) == "done"
+        vmm_ops.unmap_from_kv_tensors([PAGE])
+        vmm_ops.shutdown_kvcached()
+        q.put("bye")
+    except Exception as e:
+        q.put(("ERR", repr(e)))
+
+
+def test_shared_pool_between_two_processes(vmm):
+    """north-star TP sharing: rank 0 backs a page id with exportable handles, exports one POSIX fd per slot
+    (hipMemExportToShareableHandle), ships them with SCM_RIGHTS over the worker's Unix socket; the peer
+    imports (hipMemImportFromShareableHandle) and maps them at the same offsets. Both see the same bytes."""
+    import multiprocessing as mp
+    ops, capi = vmm["ops"], vmm["capi"]
+    ipc = os.environ["KVCACHED_IPC_NAME"]
+    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from kvcached_amd import tp_ipc_util as tp
+    peer = ctx.Process(target=_peer_process, args=(tp.get_worker_socket_path(1), ipc, q))
+    try:
+        peer.start()
+        ops.init_kvcached(DEV, PAGE, False)
+        ts = ops.create_kv_tensors(16 * MiB, 2, DEV, 2, 2, 0, False)
+        msg = q.get(timeout=180)
+        assert msg == "ready", msg
+        assert ops.map_to_kv_tensors([PAGE])
+        epp = PAGE // 2
+        k = 0
+        for t in ts:
+            for half in (0, t.numel() // 2):
+                k += 1
+                t[half + epp + 7] = 1000 + k
+        torch.cuda.synchronize()
+        tp.share_mapped_slots(2, [PAGE], pp_rank=0, group_id=0, src_rank=0)   # export + SCM_RIGHTS + peer maps
+        q.put("mapped")
+        msg = q.get(timeout=120)
+        assert msg == ("peer_sees", [1001, 1002, 1003, 1004]), msg
+        torch.cuda.synchronize()
+        assert int(ts[1][epp + 9]) == 777
+        q.put("done")
+        assert q.get(timeout=120) == "bye"
+        assert ops.unmap_from_kv_tensors([PAGE])
+    finally:
+        os.environ.pop("KVCACHED_EXPORTABLE_HANDLES", None)
+        tp._channels.close()
+        peer.join(timeout=60)
+        if peer.is_alive():
+            peer.kill()
