@@ -344,6 +344,32 @@ def gen_layouts():
     dump("alloc_kv_cache_layouts.json", {"meta": META, "page_size": PAGE, "cases": cases})
 
 
+# ------------------------------------------------------------------ 5. ElasticBlockPool (prefix cache layer)
+def gen_prefix_cache():
+    """Builds the reference's ElasticBlockPool exactly like its own tests/test_prefix_cache.py does (its patch's
+    inject method on a fake block_pool module, get_kv_cache_manager patched to hand out a fake manager) and records
+    what it does on seeded request traces."""
+    import types
+    from unittest import mock
+    import kvcached.integration.vllm.interfaces  # noqa: F401  (resolvable target for mock.patch)
+    from kvcached.integration.vllm.patches import ElasticBlockPoolPatch, _make_cache_key
+    cases = []
+    for c in kvc_traces.PREFIX_CACHE_CASES:
+        manager = T.FifoBlockManager(c["num_blocks"])
+        mod = types.ModuleType("fake_block_pool")
+        mod.BlockPool, mod.KVCacheBlock = T.FakeBlockPool, T.FakeKVCacheBlock
+        with mock.patch("kvcached.integration.vllm.interfaces.get_kv_cache_manager", return_value=manager):
+            ElasticBlockPoolPatch().inject_elastic_block_pool(mod)
+            pool = mod.ElasticBlockPool(num_gpu_blocks=c["num_blocks"], block_size=16, cell_size=1024, num_layers=1,
+                                        enable_caching=c["enable_caching"], max_cached_blocks=c["max_cached_blocks"])
+        ops = kvc_traces.prefix_cache_ops(c["n_ops"], c["seed"], c["num_blocks"])
+        recs = T.replay_prefix_cache(pool, manager, ops)
+        cases.append({"config": c, "null_block": pool.null_block.block_id, "ops": ops, "records": recs})
+    keys = [[h, g, _make_cache_key(h, g).hex()] for h, g in (("abc", 0), ("abc", 7), ("", 1))]
+    keys += [[h.hex(), g, _make_cache_key(h, g).hex()] for h, g in ((b"\x00\x01", 0), (b"hash", 65536))]
+    dump("prefix_cache.json", {"meta": META, "cache_keys": keys, "cases": cases})
+
+
 if __name__ == "__main__":
     t0 = time.time()
     print("reference module:", ref_ops.__file__ if hasattr(ref_ops, "__file__") else REF_SO)
@@ -353,4 +379,5 @@ if __name__ == "__main__":
     gen_page_allocator()
     gen_manager()
     gen_layouts()
+    gen_prefix_cache()
     print(f"done in {time.time() - t0:.1f}s")

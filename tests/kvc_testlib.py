@@ -388,3 +388,82 @@ class ProductAdapter(Adapter):
         self.tensors = None
         self.ops.shutdown_kvcached()
         capi.set_mem_info_override(0, 0)
+
+
+# --------------------------------------------------------------------------- prefix-cache harness (no vLLM)
+class FakeBlockPool:
+    """Stand-in for vllm.v1.core.block_pool.BlockPool (base class only)."""
+
+
+class FakeKVCacheBlock:
+    def __init__(self, block_id: int, ref_cnt: int = 0):
+        self.block_id, self.ref_cnt, self.is_null = block_id, ref_cnt, False
+
+
+class FakeRequest:
+    def __init__(self, block_hashes):
+        self.block_hashes = block_hashes
+
+
+class FifoBlockManager:
+    """Deterministic stand-in for KVCacheManager: hands out the lowest free ids, frees to the back."""
+
+    def __init__(self, num_blocks: int):
+        self.free_ids = list(range(num_blocks))
+
+    def alloc(self, n: int):
+        if len(self.free_ids) < n:
+            return None
+        out, self.free_ids = self.free_ids[:n], self.free_ids[n:]
+        return out
+
+    def free(self, ids):
+        self.free_ids.extend(ids)
+
+    def available_size(self) -> int:
+        return len(self.free_ids)
+
+
+def replay_prefix_cache(pool, manager, ops):
+    """Drives an ElasticBlockPool like vLLM's KVCacheManager does. Ops:
+      ["req", rid, [hash ids], group]   look the prefix up (all-or-nothing per block), touch the hits, allocate the
+                                        rest, register the full blocks                          -> block ids | error
+      ["fin", rid]                      free the request's blocks in reverse order
+      ["evict", [ids]] / ["reset"] / ["stat"]
+    Returns one record per op: result + (num_free_blocks, evictable ids in LRU order, #cached keys, manager free list)."""
+    live, out = {}, []
+    for op in ops:
+        r = None
+        try:
+            if op[0] == "req":
+                _, rid, hashes, group = op
+                hs = [b"h%06d" % h for h in hashes]
+                hits = []
+                for h in hs:
+                    got = pool.get_cached_block(h, [group])
+                    if not got:
+                        break
+                    hits.append(got[0])
+                if hits:
+                    pool.touch(hits)
+                need = len(hs) - len(hits)
+                new = pool.get_new_blocks(need) if need else []
+                blocks = hits + new
+                pool.cache_full_blocks(FakeRequest(hs), blocks, len(hits), len(blocks), 16, group)
+                live[rid] = blocks
+                r = {"hit": len(hits), "ids": [b.block_id for b in blocks]}
+            elif op[0] == "fin":
+                blocks = live.pop(op[1], [])
+                pool.free_blocks(reversed(blocks))
+            elif op[0] == "evict":
+                pool.evict_blocks(set(op[1]))
+            elif op[0] == "reset":
+                r = pool.reset_prefix_cache()
+            elif op[0] == "stat":
+                r = [pool.get_num_free_blocks(), round(pool.get_usage(), 9), len(pool.take_events())]
+        except ValueError as e:
+            r = "ValueError: " + str(e)
+        out.append({"r": r, "s": [pool.get_num_free_blocks(), list(getattr(pool, "_evictable_blocks", {}).keys()),
+                                  len(getattr(pool, "_cached_blocks", {})), h64(manager.free_ids),
+                                  [b.ref_cnt for bl in live.values() for b in bl][:16]]})
+    return out

@@ -221,3 +221,42 @@ LAYOUT_CASES: List[Dict[str, Any]] = [
     dict(engine="sglang", attention_type="MLA", shape=[1000, 1, 576], block_size=64, dtype="bfloat16", num_layers=27,
          gpu_bytes=5 * GiB, contiguous=True),
 ]
+
+
+# ------------------------------------------------------------------ prefix cache (ElasticBlockPool)
+def prefix_cache_ops(n_ops: int, seed: int, num_blocks: int, n_prefixes: int = 12):
+    """Requests share prefixes drawn from a small catalogue, so hits, LRU eviction under pressure, capped
+    evictable sets and failed allocations all occur."""
+    rng = np.random.default_rng(seed)
+    catalogue = [[int(p * 1000 + i) for i in range(int(rng.integers(2, 14)))] for p in range(n_prefixes)]
+    ops, live, nxt, uniq = [], [], 0, 500000
+    for _ in range(n_ops):
+        u = rng.random()
+        if u < 0.5 or not live:
+            base = catalogue[int(rng.integers(n_prefixes))]
+            cut = int(rng.integers(1, len(base) + 1))
+            tail = int(rng.integers(0, 4))
+            hashes = base[:cut] + [uniq + i for i in range(tail)]
+            uniq += tail
+            ops.append(["req", nxt, hashes, int(rng.integers(0, 2)) if rng.random() < 0.2 else 0])
+            live.append(nxt)
+            nxt += 1
+        elif u < 0.85:
+            ops.append(["fin", live.pop(int(rng.integers(len(live))))])
+        elif u < 0.92:
+            ops.append(["evict", [int(x) for x in rng.choice(num_blocks, size=int(rng.integers(1, 6)), replace=False)]])
+        elif u < 0.95:
+            ops.append(["reset"])
+        else:
+            ops.append(["stat"])
+    return ops
+
+
+PREFIX_CACHE_CASES = [
+    dict(name="default_cap_1000", num_blocks=64, enable_caching=True, max_cached_blocks=1000, seed=21, n_ops=400),
+    dict(name="unlimited", num_blocks=48, enable_caching=True, max_cached_blocks=-1, seed=22, n_ops=400),
+    dict(name="cap_5", num_blocks=64, enable_caching=True, max_cached_blocks=5, seed=23, n_ops=400),
+    dict(name="cap_0_evict_on_free", num_blocks=64, enable_caching=True, max_cached_blocks=0, seed=24, n_ops=300),
+    dict(name="caching_off", num_blocks=64, enable_caching=False, max_cached_blocks=1000, seed=25, n_ops=300),
+    dict(name="tiny_pool_pressure", num_blocks=20, enable_caching=True, max_cached_blocks=1000, seed=26, n_ops=400),
+]
