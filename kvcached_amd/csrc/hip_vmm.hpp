@@ -62,6 +62,12 @@ inline hipMemAccessDesc make_rw_access(int dev) {
   return d;
 }
 
+// Test hook: when >= 0, the (n+1)-th hipMemCreate from now fails with hipErrorOutOfMemory (option 104).
+inline std::atomic<int64_t> &fail_after_creates() {
+  static std::atomic<int64_t> v{-1};
+  return v;
+}
+
 struct VmmCounters {
   std::atomic<int64_t> created{0}, released{0}, reused{0};
 };
@@ -108,6 +114,8 @@ public:
     }
     Phys p;
     auto prop = make_alloc_prop(dev_, exportable_);
+    if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
+      hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
     HIP_CHECK(hipMemCreate(&p.h, granule_, &prop, 0));
     p.seq = next_seq_.fetch_add(1) + 1;
     ctr_->created++;

@@ -223,30 +223,41 @@ class KVCacheManager:
 
         out: List[int] = []
         missing = need_size
+        from_reserved = 0
         if self.reserved_blocks:
             take = min(len(self.reserved_blocks), missing)
             out = self.reserved_blocks[:take]
             self.reserved_blocks = self.reserved_blocks[take:]
             missing -= take
+            from_reserved = take
 
         bms = self.block_mem_size
-        while missing > 0:
-            if self.avail_pages:
-                _, page = self.avail_pages.popitem()  # most recently touched partial page
-            else:
-                page = self.page_allocator.alloc_page()
-                page.init(bms)
-                if page.num_free_blocks() == 0:
-                    # every aligned block of this page straddles its edge: park it where free()
-                    # can still find it and take another page
-                    self.full_pages[page.page_id] = page
-                    continue
-                self.num_avail_blocks += page.num_free_blocks()
-            take = min(page.num_free_blocks(), missing)
-            out.extend(page.alloc(take))
-            (self.full_pages if page.full() else self.avail_pages)[page.page_id] = page
-            self.num_avail_blocks -= take
-            missing -= take
+        try:
+            while missing > 0:
+                if self.avail_pages:
+                    _, page = self.avail_pages.popitem()  # most recently touched partial page
+                else:
+                    page = self.page_allocator.alloc_page()
+                    page.init(bms)
+                    if page.num_free_blocks() == 0:
+                        # every aligned block of this page straddles its edge: park it where free()
+                        # can still find it and take another page
+                        self.full_pages[page.page_id] = page
+                        continue
+                    self.num_avail_blocks += page.num_free_blocks()
+                take = min(page.num_free_blocks(), missing)
+                out.extend(page.alloc(take))
+                (self.full_pages if page.full() else self.avail_pages)[page.page_id] = page
+                self.num_avail_blocks -= take
+                missing -= take
+        except Exception:
+            # Backing a page failed (driver error, worker down). The reference never gets here with a GPU
+            # error (it aborts the process) and would leak what this call had already taken; give it back.
+            taken_from_pages = out[from_reserved:]
+            self.reserved_blocks = out[:from_reserved] + self.reserved_blocks
+            if taken_from_pages:
+                self.free(taken_from_pages)
+            raise
         return out
 
     @synchronized

@@ -277,3 +277,40 @@ def test_compact_moves_live_blocks_and_releases_pages(monkeypatch, contiguous):
         del m
     finally:
         vmm_ops.shutdown_kvcached()
+
+
+# ------------------------------------------------------------------ failure path
+def test_driver_failure_rolls_the_batch_back(monkeypatch):
+    """The (n+1)-th hipMemCreate of a map batch fails (injected hipErrorOutOfMemory): the reference would abort()
+    the process (csrc/inc/gpu_vmm.hpp:37-45); here the batch is undone, alloc_page rolls the page id back
+    (page_allocator.cpp:215-224 finally reachable), alloc() raises RuntimeError naming the page, and the very same
+    allocation succeeds afterwards with the same block ids."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    capi.set_option(capi.OPT_POOL_BYTES, 0)             # every handle must be created
+    try:
+        raw = vmm_ops.create_kv_tensors(16 * T.PAGE * 2, 1, DEV, 4, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=16 * 64, block_size=16, cell_size=2048, num_layers=4)
+        assert m._post_init_done.wait(10)
+        first = m.alloc(10)
+        before = (m.available_size(), m.page_allocator.get_num_free_pages(), m.page_allocator._page_list(0))
+        capi.reset_stats()
+        capi.set_option(104, 5)                         # page id 1 needs 8 slots; the 6th create fails
+        with pytest.raises(RuntimeError, match=r"Failed to map page 1: .*hipMemCreate.*\[injected\]"):
+            m.alloc(100)
+        capi.set_option(104, -1)
+        st = capi.get_stats()
+        assert st["handles_created"] == 5 and st["handles_released"] == 5      # the partial batch was undone
+        after = (m.available_size(), m.page_allocator.get_num_free_pages(), m.page_allocator._page_list(0))
+        assert after == before
+        # nothing of page 1 is left mapped (lazy mode: it can be mapped again from scratch), and the retry works
+        got = m.alloc(100)
+        assert got == list(range(10, 110))
+        assert int(torch.count_nonzero(raw[0][T.PAGE:2 * T.PAGE])) == 0
+        m.free(first + got)
+        del m
+    finally:
+        capi.set_option(104, -1)
+        vmm_ops.shutdown_kvcached()

@@ -204,6 +204,41 @@ def test_clear_and_null_block(cpu_ops):
     del m
 
 
+def test_alloc_is_exception_safe_when_backing_a_page_fails(cpu_ops):
+    """A worker (or the driver) fails while the 2nd page of an alloc() is being backed: alloc() raises, and the
+    blocks it had already taken from the partially used page and from the reservation are given back — the same
+    call succeeds with the same ids once the fault is gone. (The reference leaks them: its loop at
+    kvcached/kv_cache_manager.py:279-304 has no unwinding; with GPU errors it aborts before that matters.)
+    The GPU twin with an injected hipMemCreate failure is tests/test_gpu_manager.py."""
+    ops, capi = cpu_ops
+    import kvcached_amd.kv_cache_manager as kcm
+    ops.create_kv_tensors(16 * PAGE * 2, 1, "cpu", 2, 2, 0, False)
+    m = kcm.KVCacheManager(num_blocks=16 * 64, block_size=16, cell_size=2048, num_layers=2)
+    assert m._post_init_done.wait(10)
+    first = m.alloc(10)
+    assert m.try_to_reserve(4) and m.reserved_blocks == [10, 11, 12, 13]
+    before = (m.available_size(), list(m.reserved_blocks), m.page_allocator.get_num_free_pages(),
+              m.page_allocator._page_list(0), m.num_avail_blocks)
+    pa = m.page_allocator
+    pa.set_should_use_worker_ipc_callback(lambda: True)
+
+    def boom(ws, offs):
+        raise ValueError("worker down")
+    pa.set_broadcast_map_callback(boom)
+    with pytest.raises(RuntimeError, match="Failed to map page 1"):
+        m.alloc(100)
+    after = (m.available_size(), list(m.reserved_blocks), m.page_allocator.get_num_free_pages(),
+             m.page_allocator._page_list(0), m.num_avail_blocks)
+    assert after == before
+    pa.set_broadcast_map_callback(None)
+    pa.set_should_use_worker_ipc_callback(None)
+    got = m.alloc(100)
+    assert got == list(range(10, 110))
+    m.free(first + got)
+    assert m.page_allocator.get_num_inuse_pages() == 0
+    del m
+
+
 def test_config_error_for_oversized_blocks(cpu_ops):
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd.utils import KVCachedConfigError
