@@ -120,6 +120,7 @@ int kvc_set_option(int opt, int64_t value) {
   case KVC_OPT_TLB_SHOOTDOWN: options().tlb_shootdown = value; break;
   case 102: options().access_run_slots = value; break; // tuning only
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
+  case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
   case 104: fail_after_creates() = value; break;       // fault injection: the (value+1)-th hipMemCreate fails
   case 100: options().fill_variant = value; break;    // tuning only
   case 101: options().compact_variant = value; break; // tuning only
@@ -136,6 +137,7 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
   case 102: return options().access_run_slots;
   case 103: return options().zero_alias_fanout;
+  case 105: return options().fill_chunk_slots;
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;

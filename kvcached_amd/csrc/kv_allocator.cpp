@@ -196,6 +196,16 @@ void GpuContext::tlb_shootdown() {
   // allocation that reaches the kernel driver (measured: 4 KiB has no effect, 2 MiB ~0.22 ms).
   HIP_CHECK(hipMalloc(&p, 2u << 20));
   HIP_CHECK(hipFree(p));
+  if (now_ns() - t0 < 20000) {
+    // A real trip to the kernel driver takes >150 us on MI355X (profiles/r01_remap_diag_tlb.log). Faster
+    // than 20 us means the runtime served the block from a cache and nothing was invalidated (other
+    // candidates - host-page registration, small blocks - are cached that way, profiles/r02_tlb_triggers.log):
+    // a block too large for any cache is the fallback.
+    static std::atomic<bool> warned{false};
+    if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: 2 MiB allocation did not reach the driver; using 64 MiB blocks");
+    HIP_CHECK(hipMalloc(&p, 64u << 20));
+    HIP_CHECK(hipFree(p));
+  }
   stats().tlb_shootdowns++;
   stats().shootdown_ns += now_ns() - t0;
 }
@@ -233,6 +243,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
+  options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));
   g_device = parse_device(dev_str);
   g_contiguous = contiguous_layout;
   if (g_device.is_gpu) {
@@ -551,7 +562,7 @@ bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
 }
 
 // The hot loop. Per slot: [unmap the zero alias] -> pooled handle -> hipMemMap; per contiguous run: one
-// hipMemSetAccess; per <=256 access-enabled pages: one zero_fill_pages launch that runs on the GPU while
+// hipMemSetAccess; per chunk (KVCACHED_FILL_CHUNK_SLOTS, 1024): zero_fill_pages launches (<=256 pages each) that run on the GPU while
 // the host keeps issuing driver calls for the next slots; one stream sync at the end.
 void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported) {
   if (slots.empty()) return;
@@ -582,20 +593,22 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   bool launched = false;
   size_t next_import = 0;
 
-  // Pages become usable in chunks: driver calls for <=256 slots, ONE TLB shootdown, then the fill kernel
+  // Pages become usable in chunks: driver calls for <=`chunk` slots, ONE TLB shootdown (its cost grows only
+  // mildly with the number of new mappings: 0.31 ms @256, 0.40 ms @1024), then the fill kernel
   // for exactly those slots runs on the GPU while the host issues the driver calls of the next chunk.
   bool dirty_tlb = false; // driver calls issued since the last shootdown
+  const size_t chunk = (size_t)std::max<int64_t>(1, options().fill_chunk_slots.load());
   auto launch_pending = [&](bool all) {
     size_t i = 0;
-    while (pending.size() - i >= (size_t)kMaxPtrsPerLaunch || (all && i < pending.size())) {
-      size_t k = std::min<size_t>(kMaxPtrsPerLaunch, pending.size() - i);
+    while (pending.size() - i >= chunk || (all && i < pending.size())) {
+      const size_t end = i + std::min(chunk, pending.size() - i);
       if (dirty_tlb) {
         ctx->tlb_shootdown();
         dirty_tlb = false;
       }
-      ctx->zero_fill(pending.data() + i, k, ps, nullptr);
+      for (; i < end; i += std::min<size_t>(kMaxPtrsPerLaunch, end - i))
+        ctx->zero_fill(pending.data() + i, std::min<size_t>(kMaxPtrsPerLaunch, end - i), ps, nullptr);
       launched = true;
-      i += k;
     }
     pending.erase(pending.begin(), pending.begin() + i);
   };

@@ -28,6 +28,7 @@ struct Options {
   std::atomic<int64_t> tlb_shootdown{1};
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
+  std::atomic<int64_t> fill_chunk_slots{1024}; // slots made usable (one TLB shootdown + fill launches) at a time
   std::atomic<int64_t> fill_variant{0};
   std::atomic<int64_t> compact_variant{0};
 };

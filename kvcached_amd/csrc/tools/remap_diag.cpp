@@ -64,11 +64,59 @@ static void flush_trigger(int mode) {
   }
   case 8: CK(hipMalloc(&p, 2u << 20)); CK(hipFree(p)); break;           // 2 MiB device alloc + free
   case 9: CK(hipMalloc(&p, 64u << 20)); break;                          // alloc only (leaks; map ioctl only)
+  case 10: {                                                            // register + unregister one host page
+    static char *page = (char *)aligned_alloc(4096, 4096);
+    CK(hipHostRegister(page, 4096, hipHostRegisterDefault));
+    CK(hipHostUnregister(page));
+    break;
+  }
+  case 11: {                                                            // register only (fresh page each time)
+    static char *buf = (char *)aligned_alloc(4096, 4096 * 64);
+    static int k = 0;
+    buf[4096 * k] = 1;
+    CK(hipHostRegister(buf + 4096 * k++, 4096, hipHostRegisterDefault));
+    break;
+  }
+  case 12: {                                                            // unregister only (registered up front)
+    static char *buf = nullptr;
+    static int k = 0;
+    if (!buf) {
+      buf = (char *)aligned_alloc(4096, 4096 * 64);
+      for (int i = 0; i < 64; i++) { buf[4096 * i] = 1; CK(hipHostRegister(buf + 4096 * i, 4096, hipHostRegisterDefault)); }
+      t0 = std::chrono::steady_clock::now();
+    }
+    CK(hipHostUnregister(buf + 4096 * k++));
+    break;
+  }
+  case 13: CK(hipMalloc(&p, 2u << 20)); break;                          // 2 MiB alloc only (leaks)
+  case 14: {                                                            // free only (allocated up front)
+    static std::vector<void *> blocks;
+    if (blocks.empty()) {
+      for (int i = 0; i < 64; i++) { void *q; CK(hipMalloc(&q, 2u << 20)); blocks.push_back(q); }
+      t0 = std::chrono::steady_clock::now();
+    }
+    CK(hipFree(blocks.back()));
+    blocks.pop_back();
+    break;
+  }
+  case 15: CK(hipHostMalloc(&p, 4096, 0)); CK(hipHostFree(p)); break;   // small pinned host alloc + free
+  case 16: CK(hipExtMallocWithFlags(&p, 2u << 20, hipDeviceMallocFinegrained)); CK(hipFree(p)); break;
+  case 17: CK(hipExtMallocWithFlags(&p, 2u << 20, hipDeviceMallocUncached)); CK(hipFree(p)); break;
+  case 18: {                                                            // managed range migrated back and forth
+    static char *m = nullptr;
+    static int flip = 0;
+    if (!m) { CK(hipMallocManaged((void **)&m, 2u << 20, hipMemAttachGlobal)); m[0] = 1; t0 = std::chrono::steady_clock::now(); }
+    CK(hipMemPrefetchAsync(m, 2u << 20, (flip++ & 1) ? hipCpuDeviceId : 0, 0));
+    CK(hipStreamSynchronize(0));
+    break;
+  }
+  case 19: CK(hipMalloc(&p, 1u << 20)); CK(hipFree(p)); break;          // 1 MiB
+  case 20: CK(hipMalloc(&p, 256u << 10)); CK(hipFree(p)); break;        // 256 KiB
   default: return;
   }
   double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   static int n = 0;
-  if (n++ < 2) printf("  [flush_trigger mode %d took %.1f us]\n", mode, us);
+  if (n++ < 4) printf("  [flush_trigger mode %d took %.1f us]\n", mode, us);
 }
 
 struct Ctx {
