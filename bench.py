@@ -240,21 +240,27 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import kvc_testlib as T
     lib = T.load_oracle()
-    batches = 6
+    batches = 24                                                       # ~10 s of single-core work on the GPU box
     size = batches * BATCH_PAGES * PAGE
-    buf = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    buf = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)   # reserved, committed on first touch
     anchor = ctypes.c_char.from_buffer(buf)
     base = ctypes.addressof(anchor)
     pa = T.OraclePA.create(lib, 1, size, PAGE, num_kv_buffers=1, max_res=0, min_res=0)
-    t0 = time.perf_counter()
+    dt = 0.0
     for b in range(batches):
+        t0 = time.perf_counter()
         pids = [pa.alloc_page() for _ in range(BATCH_PAGES)]           # bookkeeping
         ev = pa.drain_events()
         offs = [o for _, os_ in ev for o in os_]
         assert len(offs) == BATCH_PAGES and len(pids) == BATCH_PAGES
         ptrs = (ctypes.c_void_p * BATCH_PAGES)(*[base + o for o in offs])
         lib.okvc_zero_fill_pages(ptrs, BATCH_PAGES, PAGE)               # "map" is a no-op on the cpu device
-    dt = time.perf_counter() - t0
+        dt += time.perf_counter() - t0
+        buf.madvise(mmap.MADV_DONTNEED, min(offs), BATCH_PAGES * PAGE)  # untimed: keep the resident set at one batch
+        done = b + 1
+        if dt > 12.0:                                                   # bounded sample on a slow host
+            break
+    batches = done
     pa.close()
     del ptrs, anchor
     buf.close()
