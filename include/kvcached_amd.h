@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KVC_ABI_VERSION 1
+#define KVC_ABI_VERSION 2
 
 enum {
   KVC_OK = 0,
@@ -99,6 +99,7 @@ typedef struct kvc_stats {
   double compact_ms;
   int64_t tlb_shootdowns;                     /* explicit GPU TLB invalidations (see KVC_OPT_TLB_SHOOTDOWN) */
   int64_t shootdown_ns;                       /* host wall time spent in them */
+  int64_t index_launches;                     /* block id <-> token index kernels (kvc_expand_block_ids ...) */
 } kvc_stats_t;
 int kvc_get_stats(kvc_stats_t *out);
 int kvc_reset_stats(void);
@@ -187,6 +188,33 @@ int kvc_compact_blocks(void *const *region_bases, size_t n_regions, const int64_
 /* Region bases of a group's KV tensors in map order (layer-major, K then V), for compact_blocks.
  * Returns the count; copies if cap suffices. */
 int64_t kvc_get_region_bases(int64_t group_id, void **out, int64_t cap);
+
+/* ------------------------------------------------------------------ block ids <-> token slot indices
+ * The step right after KVCacheManager.alloc() / before KVCacheManager.free() in the SGLang token-pool
+ * allocators; replaces the torch/Triton glue of the reference's ElasticTokenToKVPoolAllocator and
+ * ElasticPagedTokenToKVPoolAllocator (kvcached/integration/sglang/patches.py:100-117,186-276).
+ * `block_ids` / `new_block_ids` are HOST arrays (what alloc() returned); every other pointer is device
+ * memory (int64). Asynchronous on `stream` (NULL = the library's stream) unless stated otherwise.
+ *
+ * kvc_expand_block_ids      out[i*tpb + j] = block_ids[i]*tpb + j             (patches.py:188-197; tpb = 1: :100-102)
+ * kvc_alloc_extend_indices  request r grows from prefix_lens[r] to seq_lens[r] tokens: tokens that still fit its
+ *                           last block continue after last_loc[r], the others fill its share of new_block_ids in
+ *                           order; requests back to back in out[extend_num_tokens]   (patches.py:199-243 +
+ *                           SGLang's alloc_extend_kernel)
+ * kvc_alloc_decode_indices  one new token per request: a new block iff (seq_lens[r]-1) % tpb == 0, else
+ *                           last_loc[r]+1; out[bs]                              (patches.py:245-276 + alloc_decode_kernel)
+ * kvc_unique_block_ids      BLOCKING. Distinct blocks of n token indices, ascending = torch.unique(idx // tpb)
+ *                           (patches.py:278-288), into the host array out_host[cap]; returns the count (copied only
+ *                           if it fits) or KVC_E_INVALID if an index is outside [0, num_blocks*tpb). */
+int kvc_expand_block_ids(const int64_t *block_ids, size_t n, int64_t tokens_per_block, int64_t *out_dev, void *stream);
+int kvc_alloc_extend_indices(const int64_t *prefix_lens_dev, const int64_t *seq_lens_dev, const int64_t *last_loc_dev,
+                             size_t bs, const int64_t *new_block_ids, size_t n_new, int64_t tokens_per_block,
+                             int64_t *out_dev, size_t extend_num_tokens, void *stream);
+int kvc_alloc_decode_indices(const int64_t *seq_lens_dev, const int64_t *last_loc_dev, size_t bs,
+                             const int64_t *new_block_ids, size_t n_new, int64_t tokens_per_block, int64_t *out_dev,
+                             void *stream);
+int64_t kvc_unique_block_ids(const int64_t *token_indices_dev, size_t n, int64_t tokens_per_block, int64_t num_blocks,
+                             int64_t *out_host, size_t cap, void *stream);
 
 /* ------------------------------------------------------------------ TP shared pool (north-star addition;
  * the reference has no memory sharing — kvcached/tp_ipc_util.py only broadcasts offsets).

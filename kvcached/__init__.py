@@ -23,8 +23,10 @@ _ALIASES = {
     "kvcached.integration": "kvcached_amd.integration",
     "kvcached.integration.vllm": "kvcached_amd.integration.vllm",
     "kvcached.integration.vllm.interfaces": "kvcached_amd.integration.vllm.interfaces",
+    "kvcached.integration.vllm.block_pool": "kvcached_amd.integration.vllm.block_pool",
     "kvcached.integration.sglang": "kvcached_amd.integration.sglang",
     "kvcached.integration.sglang.interfaces": "kvcached_amd.integration.sglang.interfaces",
+    "kvcached.integration.sglang.allocators": "kvcached_amd.integration.sglang.allocators",
 }
 for _alias, _target in _ALIASES.items():
     _mod = importlib.import_module(_target)

@@ -41,7 +41,7 @@ class Stats(ctypes.Structure):
                 ("map_calls", _i64), ("unmap_calls", _i64), ("map_ns", _i64), ("unmap_ns", _i64),
                 ("fill_launches", _i64), ("fill_bytes", _i64), ("fill_ms", ctypes.c_double),
                 ("compact_launches", _i64), ("compact_bytes", _i64), ("compact_ms", ctypes.c_double),
-                ("tlb_shootdowns", _i64), ("shootdown_ns", _i64)]
+                ("tlb_shootdowns", _i64), ("shootdown_ns", _i64), ("index_launches", _i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -106,6 +106,10 @@ SIGNATURES = {
     "kvc_zero_fill_pages": (_int, [_VPP, _sz, _sz, _vp, _int]),
     "kvc_compact_blocks": (_int, [_VPP, _sz, _I64P, _I64P, _sz, _sz, _vp, _int]),
     "kvc_get_region_bases": (_i64, [_i64, _VPP, _i64]),
+    "kvc_expand_block_ids": (_int, [_I64P, _sz, _i64, _vp, _vp]),
+    "kvc_alloc_extend_indices": (_int, [_vp, _vp, _vp, _sz, _I64P, _sz, _i64, _vp, _sz, _vp]),
+    "kvc_alloc_decode_indices": (_int, [_vp, _vp, _sz, _I64P, _sz, _i64, _vp, _vp]),
+    "kvc_unique_block_ids": (_i64, [_vp, _sz, _i64, _i64, _I64P, _sz, _vp]),
     "kvc_export_mapped_slots": (_int, [_I64P, _sz, _i64, _INTP, _i64]),
     "kvc_map_imported_slots": (_int, [_I64P, _sz, _i64, _INTP, _sz]),
 }
@@ -222,6 +226,32 @@ def get_region_bases(group_id: int = 0) -> List[int]:
     buf = (ctypes.c_void_p * max(1, n))()
     check(lib.kvc_get_region_bases(group_id, buf, n))
     return [int(buf[i] or 0) for i in range(n)]
+
+
+# ---- block ids <-> token slot indices. Device arrays are passed as raw addresses (tensor.data_ptr()),
+# `stream` as the raw hipStream_t (torch.cuda.current_stream().cuda_stream); 0 = the library's own stream.
+def expand_block_ids(block_ids: Sequence[int], tokens_per_block: int, out_ptr: int, stream: int = 0) -> None:
+    check(lib.kvc_expand_block_ids(i64_array(block_ids), len(block_ids), tokens_per_block, out_ptr, stream))
+
+
+def alloc_extend_indices(prefix_lens_ptr: int, seq_lens_ptr: int, last_loc_ptr: int, bs: int, new_block_ids: Sequence[int],
+                         tokens_per_block: int, out_ptr: int, extend_num_tokens: int, stream: int = 0) -> None:
+    check(lib.kvc_alloc_extend_indices(prefix_lens_ptr, seq_lens_ptr, last_loc_ptr, bs, i64_array(new_block_ids),
+                                       len(new_block_ids), tokens_per_block, out_ptr, extend_num_tokens, stream))
+
+
+def alloc_decode_indices(seq_lens_ptr: int, last_loc_ptr: int, bs: int, new_block_ids: Sequence[int], tokens_per_block: int,
+                         out_ptr: int, stream: int = 0) -> None:
+    check(lib.kvc_alloc_decode_indices(seq_lens_ptr, last_loc_ptr, bs, i64_array(new_block_ids), len(new_block_ids),
+                                       tokens_per_block, out_ptr, stream))
+
+
+def unique_block_ids(token_indices_ptr: int, n: int, tokens_per_block: int, num_blocks: int, stream: int = 0) -> List[int]:
+    """Blocking. Sorted distinct block ids of n device token indices."""
+    cap = min(n, num_blocks)
+    out = (_i64 * max(1, cap))()
+    cnt = check(lib.kvc_unique_block_ids(token_indices_ptr, n, tokens_per_block, num_blocks, out, cap, stream))
+    return list(out[:cnt])
 
 
 def export_mapped_slots(offsets: Sequence[int], group_id: int = 0) -> List[int]:

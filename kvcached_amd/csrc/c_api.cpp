@@ -163,6 +163,7 @@ int kvc_get_stats(kvc_stats_t *o) {
   o->compact_bytes = s.compact_bytes;
   o->tlb_shootdowns = s.tlb_shootdowns;
   o->shootdown_ns = s.shootdown_ns;
+  o->index_launches = s.index_launches;
   std::lock_guard<std::mutex> g(s.mu);
   o->fill_ms = s.fill_ms;
   o->compact_ms = s.compact_ms;
@@ -364,6 +365,63 @@ int64_t kvc_get_region_bases(int64_t group_id, void **out, int64_t cap) {
     auto b = KvAllocator::global(group_id)->region_bases();
     if (out && cap >= (int64_t)b.size()) std::copy(b.begin(), b.end(), out);
     return (int64_t)b.size();
+  });
+}
+
+// ---------------------------------------------------------------- block ids <-> token indices
+namespace {
+GpuContext *index_ctx(const char *what) {
+  GpuContext *ctx = KvAllocator::gpu();
+  if (!ctx) throw NoGpuError(std::string(what) + " needs init_kvcached on a GPU device");
+  ctx->bind();
+  return ctx;
+}
+} // namespace
+
+int kvc_expand_block_ids(const int64_t *block_ids, size_t n, int64_t tpb, int64_t *out_dev, void *stream) {
+  return guarded([&]() -> int {
+    GpuContext *ctx = index_ctx("expand_block_ids");
+    if (tpb <= 0 || tpb > 0x7fffffff) throw InvalidError("tokens_per_block must be in [1, 2^31)");
+    if (n && (!block_ids || !out_dev)) throw InvalidError("NULL argument");
+    ctx->expand_block_ids(block_ids, n, tpb, out_dev, static_cast<hipStream_t>(stream));
+    return KVC_OK;
+  });
+}
+
+int kvc_alloc_extend_indices(const int64_t *prefix_lens_dev, const int64_t *seq_lens_dev, const int64_t *last_loc_dev,
+                             size_t bs, const int64_t *new_block_ids, size_t n_new, int64_t tpb, int64_t *out_dev,
+                             size_t extend_num_tokens, void *stream) {
+  return guarded([&]() -> int {
+    GpuContext *ctx = index_ctx("alloc_extend_indices");
+    if (tpb <= 0 || tpb > 0x7fffffff) throw InvalidError("tokens_per_block must be in [1, 2^31)");
+    if (bs && (!prefix_lens_dev || !seq_lens_dev || !last_loc_dev)) throw InvalidError("NULL argument");
+    if ((n_new && !new_block_ids) || (extend_num_tokens && !out_dev)) throw InvalidError("NULL argument");
+    if (extend_num_tokens > (size_t)65535 * 4096) throw InvalidError("extend_num_tokens too large for one call");
+    ctx->alloc_extend_indices(prefix_lens_dev, seq_lens_dev, last_loc_dev, bs, new_block_ids, n_new, tpb, out_dev,
+                              extend_num_tokens, static_cast<hipStream_t>(stream));
+    return KVC_OK;
+  });
+}
+
+int kvc_alloc_decode_indices(const int64_t *seq_lens_dev, const int64_t *last_loc_dev, size_t bs,
+                             const int64_t *new_block_ids, size_t n_new, int64_t tpb, int64_t *out_dev, void *stream) {
+  return guarded([&]() -> int {
+    GpuContext *ctx = index_ctx("alloc_decode_indices");
+    if (tpb <= 0 || tpb > 0x7fffffff) throw InvalidError("tokens_per_block must be in [1, 2^31)");
+    if (bs && (!seq_lens_dev || !last_loc_dev || !out_dev)) throw InvalidError("NULL argument");
+    if (n_new && !new_block_ids) throw InvalidError("NULL argument");
+    ctx->alloc_decode_indices(seq_lens_dev, last_loc_dev, bs, new_block_ids, n_new, tpb, out_dev,
+                              static_cast<hipStream_t>(stream));
+    return KVC_OK;
+  });
+}
+
+int64_t kvc_unique_block_ids(const int64_t *token_indices_dev, size_t n, int64_t tpb, int64_t num_blocks, int64_t *out_host,
+                             size_t cap, void *stream) {
+  return guarded([&]() -> int64_t {
+    GpuContext *ctx = index_ctx("unique_block_ids");
+    if (n && !token_indices_dev) throw InvalidError("NULL argument");
+    return ctx->unique_block_ids(token_indices_dev, n, tpb, num_blocks, out_host, cap, static_cast<hipStream_t>(stream));
   });
 }
 

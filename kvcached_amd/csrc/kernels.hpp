@@ -1,4 +1,5 @@
-// kernels.hpp — host-side launch interface of the two gfx950 kernels (kernels.hip).
+// kernels.hpp — host-side launch interface of the gfx950 kernels (kernels.hip: byte movers; index_kernels.hip:
+// block id <-> token index glue).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,6 +15,7 @@ static constexpr size_t kFillSlabBytes = 64 * 1024;
 static constexpr int kMaxPtrsPerLaunch = 256;
 static constexpr int kMaxRegionsPerLaunch = 128;
 static constexpr int kMaxMovesPerLaunch = 448; // 448 x 16 B + 128 x 8 B = 8 KiB of kernarg
+static constexpr int kMaxIdsPerLaunch = 1024; // block ids one index-kernel launch carries in its kernarg (8 KiB)
 
 // Zero `n` pages of `page_bytes` each (n <= kMaxPtrsPerLaunch). Asynchronous on `stream`.
 // variant: 0 = default; others are tuning variants kept for A/B runs.
@@ -26,5 +28,22 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
 // XCD-aware, 2/3 = the same two with the plain interleaved placement (A/B runs).
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant = 0);
+
+// ---- index_kernels.hip. Block ids come either from the host (`ids_host`, <= kMaxIdsPerLaunch, carried in the
+// kernarg) or from device memory (`ids_dev` != nullptr, any count). All asynchronous on `stream`.
+// out[i*tpb + j] = ids[i]*tpb + j
+hipError_t launch_expand_block_ids(const int64_t *ids_host, const int64_t *ids_dev, size_t n_ids, int64_t tpb,
+                                   int64_t *out, hipStream_t stream);
+// token slots for requests growing pre_lens[r] -> seq_lens[r] (see the kernel); out has out_len entries
+hipError_t launch_alloc_extend(const int64_t *ids_host, const int64_t *ids_dev, size_t n_ids, const int64_t *pre_lens,
+                               const int64_t *seq_lens, const int64_t *last_loc, size_t bs, int64_t tpb, int64_t *out,
+                               size_t out_len, hipStream_t stream);
+// token slot of the one new token of every request; out has bs entries
+hipError_t launch_alloc_decode(const int64_t *ids_host, const int64_t *ids_dev, size_t n_ids, const int64_t *seq_lens,
+                               const int64_t *last_loc, size_t bs, int64_t tpb, int64_t *out, hipStream_t stream);
+// result[0] = number of distinct blocks (or -(number of out-of-range indices)), result[1..] = ascending block ids.
+// `bitmap` (>= ceil(n_blocks/32) zeroed words) and `header` (16 bytes {0xffffffff,0,0,0}) are left in that state.
+hipError_t launch_unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, unsigned *bitmap,
+                                   void *header, int64_t *result, size_t cap, hipStream_t stream);
 
 } // namespace kvc

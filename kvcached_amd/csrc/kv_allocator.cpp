@@ -26,6 +26,7 @@ void Stats::reset() {
   map_calls = unmap_calls = map_ns = unmap_ns = 0;
   fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
   tlb_shootdowns = shootdown_ns = 0;
+  index_launches = 0;
   t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
   vmm.created = vmm.released = vmm.reused = 0;
   std::lock_guard<std::mutex> g(mu);
@@ -86,6 +87,9 @@ GpuContext::~GpuContext() {
   }
   pools_[0].clear();
   pools_[1].clear();
+  if (uniq_bitmap_) (void)hipFree(uniq_bitmap_);
+  if (uniq_header_) (void)hipFree(uniq_header_);
+  if (uniq_result_) (void)hipHostFree(uniq_result_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -186,6 +190,112 @@ void GpuContext::compact(void *const *bases, size_t n_regions, const int64_t *sr
       stats().compact_bytes += 2ll * nr * nm * (int64_t)block_bytes;
     }
   }
+}
+
+// ---------------------------------------------------------------- block id <-> token index glue
+namespace {
+// Block ids beyond the kernarg budget go through a stream-ordered device buffer (rare: > 1024 new blocks in
+// one scheduler step). hipMemcpyAsync from pageable memory returns once the source has been consumed.
+struct StagedIds {
+  int64_t *dev = nullptr;
+  hipStream_t s;
+  StagedIds(const int64_t *host, size_t n, hipStream_t stream) : s(stream) {
+    HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&dev), n * sizeof(int64_t), s));
+    hipError_t st = hipMemcpyAsync(dev, host, n * sizeof(int64_t), hipMemcpyHostToDevice, s);
+    if (st != hipSuccess) {
+      (void)hipFreeAsync(dev, s);
+      HIP_CHECK(st);
+    }
+  }
+  ~StagedIds() {
+    if (dev) (void)hipFreeAsync(dev, s);
+  }
+};
+} // namespace
+
+void GpuContext::expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s) {
+  if (!s) s = stream_;
+  for (size_t i = 0; i < n; i += kMaxIdsPerLaunch) {
+    const size_t k = std::min<size_t>(kMaxIdsPerLaunch, n - i);
+    HIP_CHECK(launch_expand_block_ids(ids + i, nullptr, k, tpb, out + i * (size_t)tpb, s));
+    stats().index_launches++;
+  }
+}
+
+void GpuContext::alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
+                                      const int64_t *ids, size_t n_ids, int64_t tpb, int64_t *out, size_t out_len,
+                                      hipStream_t s) {
+  if (!s) s = stream_;
+  if (n_ids <= (size_t)kMaxIdsPerLaunch) {
+    HIP_CHECK(launch_alloc_extend(ids, nullptr, n_ids, pre_lens, seq_lens, last_loc, bs, tpb, out, out_len, s));
+  } else {
+    StagedIds staged(ids, n_ids, s);
+    HIP_CHECK(launch_alloc_extend(nullptr, staged.dev, n_ids, pre_lens, seq_lens, last_loc, bs, tpb, out, out_len, s));
+  }
+  stats().index_launches++;
+}
+
+void GpuContext::alloc_decode_indices(const int64_t *seq_lens, const int64_t *last_loc, size_t bs, const int64_t *ids,
+                                      size_t n_ids, int64_t tpb, int64_t *out, hipStream_t s) {
+  if (!s) s = stream_;
+  if (n_ids <= (size_t)kMaxIdsPerLaunch) {
+    HIP_CHECK(launch_alloc_decode(ids, nullptr, n_ids, seq_lens, last_loc, bs, tpb, out, s));
+  } else {
+    StagedIds staged(ids, n_ids, s);
+    HIP_CHECK(launch_alloc_decode(nullptr, staged.dev, n_ids, seq_lens, last_loc, bs, tpb, out, s));
+  }
+  stats().index_launches++;
+}
+
+void GpuContext::reset_unique_scratch() {
+  static const unsigned init[4] = {0xffffffffu, 0u, 0u, 0u};
+  if (uniq_bitmap_) (void)hipMemset(uniq_bitmap_, 0, uniq_words_ * sizeof(unsigned));
+  if (uniq_header_) (void)hipMemcpy(uniq_header_, init, sizeof(init), hipMemcpyHostToDevice);
+}
+
+int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, int64_t *out_host,
+                                     size_t cap, hipStream_t s) {
+  if (!s) s = stream_;
+  if (tpb <= 0 || n_blocks <= 0) throw InvalidError("tokens_per_block and num_blocks must be positive");
+  std::lock_guard<std::mutex> g(uniq_mu_);
+  const size_t words = ((size_t)n_blocks + 31) / 32;
+  if (words > uniq_words_) {
+    if (uniq_bitmap_) HIP_CHECK(hipFree(uniq_bitmap_));
+    uniq_bitmap_ = nullptr;
+    uniq_words_ = 0;
+    const size_t want = std::max<size_t>(words, 4096);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&uniq_bitmap_), want * sizeof(unsigned)));
+    uniq_words_ = want;
+    if (!uniq_header_) HIP_CHECK(hipMalloc(&uniq_header_, 16));
+    reset_unique_scratch();
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  const size_t need = std::min<size_t>(n, (size_t)n_blocks) + 1;
+  if (need > uniq_result_cap_) {
+    if (uniq_result_) HIP_CHECK(hipHostFree(uniq_result_));
+    uniq_result_ = nullptr;
+    uniq_result_cap_ = 0;
+    const size_t want = std::max<size_t>(need, 8192);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&uniq_result_), want * sizeof(int64_t), hipHostMallocDefault));
+    uniq_result_cap_ = want;
+  }
+  void *result_dev = nullptr;
+  HIP_CHECK(hipHostGetDevicePointer(&result_dev, uniq_result_, 0));
+  try {
+    HIP_CHECK(launch_unique_block_ids(idx, n, tpb, n_blocks, uniq_bitmap_, uniq_header_, static_cast<int64_t *>(result_dev),
+                                      uniq_result_cap_ - 1, s));
+    stats().index_launches += 2;
+    HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) {
+    (void)hipDeviceSynchronize();
+    reset_unique_scratch();
+    throw;
+  }
+  const int64_t count = uniq_result_[0];
+  if (count < 0)
+    throw InvalidError(std::to_string(-count) + " token indices are outside [0, num_blocks * tokens_per_block)");
+  if (out_host && (size_t)count <= cap) std::copy(uniq_result_ + 1, uniq_result_ + 1 + count, out_host);
+  return count;
 }
 
 void GpuContext::tlb_shootdown() {

@@ -40,6 +40,7 @@ struct Stats {
   std::atomic<int64_t> fill_launches{0}, fill_bytes{0};
   std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
   std::atomic<int64_t> tlb_shootdowns{0}, shootdown_ns{0};
+  std::atomic<int64_t> index_launches{0};
   // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
   std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
   std::mutex mu;
@@ -66,6 +67,15 @@ public:
   void compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
                size_t block_bytes, hipStream_t s);
   void sync(hipStream_t s); // hipStreamSynchronize + harvest event timings
+  // block id <-> token index glue (index_kernels.hip); ids are HOST arrays, everything else device memory
+  void expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s);
+  void alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
+                            const int64_t *ids, size_t n_ids, int64_t tpb, int64_t *out, size_t out_len, hipStream_t s);
+  void alloc_decode_indices(const int64_t *seq_lens, const int64_t *last_loc, size_t bs, const int64_t *ids, size_t n_ids,
+                            int64_t tpb, int64_t *out, hipStream_t s);
+  // blocking: distinct blocks of `n` device token indices, ascending, into out_host; returns the count
+  int64_t unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, int64_t *out_host, size_t cap,
+                           hipStream_t s);
   // Make the driver invalidate this GPU's TLBs. hipMemMap/hipMemUnmap/hipMemSetAccess do not do it
   // on ROCm 7.2 (stale translations survive a remap: kvcached_amd/csrc/tools/remap_diag.cpp), but
   // the KFD map ioctl behind an ordinary >= 2 MiB hipMalloc does.
@@ -85,6 +95,14 @@ private:
   std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
+  // unique_block_ids scratch (grow-only; bitmap all-zero and header reset between calls)
+  std::mutex uniq_mu_;
+  unsigned *uniq_bitmap_ = nullptr;
+  size_t uniq_words_ = 0;
+  void *uniq_header_ = nullptr;
+  int64_t *uniq_result_ = nullptr; // pinned host memory the sweep kernel writes into
+  size_t uniq_result_cap_ = 0;     // entries, including the count
+  void reset_unique_scratch();
 };
 
 // One contiguous VA reservation cut into fixed-size slots (the reference's FTensor).

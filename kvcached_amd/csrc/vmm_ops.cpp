@@ -101,6 +101,64 @@ bool unmap_from_kv_tensors(const std::vector<int64_t> &offsets, int64_t group_id
   return true;
 }
 
+// ---------------------------------------------------------------- block ids <-> token indices
+// Additions to the reference surface (the fused replacement of the torch/Triton glue in
+// kvcached/integration/sglang/patches.py:186-288). Device arrays are raw addresses (tensor.data_ptr()), the
+// stream is torch's current stream handle; the id lists are read with the raw CPython API because these calls
+// sit on the scheduler's critical path (a ctypes array of 1024 ids costs 30 us to build, this 3 us).
+namespace {
+std::vector<int64_t> ids_from_sequence(py::handle seq) {
+  PyObject *fast = PySequence_Fast(seq.ptr(), "block ids must be a list or tuple of int");
+  if (!fast) throw py::error_already_set();
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  std::vector<int64_t> out((size_t)n);
+  PyObject **items = PySequence_Fast_ITEMS(fast);
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    const long long v = PyLong_AsLongLong(items[i]);
+    if (v == -1 && PyErr_Occurred()) {
+      Py_DECREF(fast);
+      throw py::error_already_set();
+    }
+    out[(size_t)i] = v;
+  }
+  Py_DECREF(fast);
+  return out;
+}
+template <class T> T *as_ptr(uintptr_t a) { return reinterpret_cast<T *>(a); }
+} // namespace
+
+void expand_block_ids(py::handle block_ids, int64_t tokens_per_block, uintptr_t out_ptr, uintptr_t stream) {
+  auto ids = ids_from_sequence(block_ids);
+  check(kvc_expand_block_ids(ids.data(), ids.size(), tokens_per_block, as_ptr<int64_t>(out_ptr), as_ptr<void>(stream)));
+}
+void alloc_extend_indices(uintptr_t prefix_lens, uintptr_t seq_lens, uintptr_t last_loc, size_t bs, py::handle new_block_ids,
+                          int64_t tokens_per_block, uintptr_t out_ptr, size_t extend_num_tokens, uintptr_t stream) {
+  auto ids = ids_from_sequence(new_block_ids);
+  check(kvc_alloc_extend_indices(as_ptr<const int64_t>(prefix_lens), as_ptr<const int64_t>(seq_lens),
+                                 as_ptr<const int64_t>(last_loc), bs, ids.data(), ids.size(), tokens_per_block,
+                                 as_ptr<int64_t>(out_ptr), extend_num_tokens, as_ptr<void>(stream)));
+}
+void alloc_decode_indices(uintptr_t seq_lens, uintptr_t last_loc, size_t bs, py::handle new_block_ids,
+                          int64_t tokens_per_block, uintptr_t out_ptr, uintptr_t stream) {
+  auto ids = ids_from_sequence(new_block_ids);
+  check(kvc_alloc_decode_indices(as_ptr<const int64_t>(seq_lens), as_ptr<const int64_t>(last_loc), bs, ids.data(), ids.size(),
+                                 tokens_per_block, as_ptr<int64_t>(out_ptr), as_ptr<void>(stream)));
+}
+py::list unique_block_ids(uintptr_t token_indices, size_t n, int64_t tokens_per_block, int64_t num_blocks, uintptr_t stream) {
+  std::vector<int64_t> out(std::max<size_t>(1, std::min<size_t>(n, (size_t)std::max<int64_t>(0, num_blocks))));
+  int64_t cnt;
+  {
+    py::gil_scoped_release nogil; // blocks until the sweep kernel's result is on the host
+    cnt = kvc_unique_block_ids(as_ptr<const int64_t>(token_indices), n, tokens_per_block, num_blocks, out.data(), out.size(),
+                               as_ptr<void>(stream));
+  }
+  if (cnt < 0) raise_last((int)cnt);
+  PyObject *l = PyList_New((Py_ssize_t)cnt);
+  if (!l) throw py::error_already_set();
+  for (int64_t i = 0; i < cnt; ++i) PyList_SET_ITEM(l, (Py_ssize_t)i, PyLong_FromLongLong(out[(size_t)i]));
+  return py::reinterpret_steal<py::list>(l);
+}
+
 // ---------------------------------------------------------------- InternalPage
 class PyInternalPage {
 public:
@@ -303,6 +361,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("map_to_kv_tensors", &map_to_kv_tensors, "map_to_kv_tensors", py::arg("offsets"), py::arg("group_id") = 0);
   m.def("unmap_from_kv_tensors", &unmap_from_kv_tensors, "unmap_from_kv_tensors", py::arg("offsets"),
         py::arg("group_id") = 0);
+
+  // additions (no reference counterpart): fused block id <-> token index glue for the SGLang allocators
+  m.def("expand_block_ids", &expand_block_ids, py::arg("block_ids"), py::arg("tokens_per_block"), py::arg("out_ptr"),
+        py::arg("stream") = 0);
+  m.def("alloc_extend_indices", &alloc_extend_indices, py::arg("prefix_lens_ptr"), py::arg("seq_lens_ptr"),
+        py::arg("last_loc_ptr"), py::arg("bs"), py::arg("new_block_ids"), py::arg("tokens_per_block"), py::arg("out_ptr"),
+        py::arg("extend_num_tokens"), py::arg("stream") = 0);
+  m.def("alloc_decode_indices", &alloc_decode_indices, py::arg("seq_lens_ptr"), py::arg("last_loc_ptr"), py::arg("bs"),
+        py::arg("new_block_ids"), py::arg("tokens_per_block"), py::arg("out_ptr"), py::arg("stream") = 0);
+  m.def("unique_block_ids", &unique_block_ids, py::arg("token_indices_ptr"), py::arg("n"), py::arg("tokens_per_block"),
+        py::arg("num_blocks"), py::arg("stream") = 0);
 
   py::class_<PyPageAllocator, std::shared_ptr<PyPageAllocator>>(m, "PageAllocator")
       .def(py::init<int64_t, int64_t, int64_t, int64_t, int64_t, bool, bool, bool, int64_t, int64_t, const std::string &>(),
