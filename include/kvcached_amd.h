@@ -81,9 +81,15 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *   KVC_OPT_TLB_SHOOTDOWN  1 (default) = after every batch of VMM map/unmap calls force the driver to
  *                              invalidate the GPU TLBs before anything touches the affected VA. On
  *                              ROCm 7.2 / MI355X hipMemMap/hipMemUnmap alone leave stale translations
- *                              behind; 0 only for measurements. */
+ *                              behind; 0 only for measurements.
+ *   KVC_OPT_DEFER_UNMAP_SHOOTDOWN 1 = the invalidation owed by an unmap batch whose pages all go back
+ *                              to the library's own handle pool waits for the next map batch (which invalidates
+ *                              before it touches anything) or for the moment handles are given back to the
+ *                              driver, whichever comes first; 0 (default) = invalidate inside every unmap call
+ *                              (the cost only moves from free() to the next alloc()).
+ *                              Compat mode (ZERO_BACKFILL) and imported pages always invalidate at once. */
 enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
-       KVC_OPT_TLB_SHOOTDOWN = 5 };
+       KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6 };
 int kvc_set_option(int opt, int64_t value);
 int64_t kvc_get_option(int opt);
 

@@ -22,7 +22,7 @@ lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
 KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, KVC_E_CALLBACK = 0, -1, -2, -3, -4, -5, -6
 KVC_E_NOT_CREATED = -7
-OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN = 1, 2, 3, 4, 5
+OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN, OPT_DEFER_UNMAP_SHOOTDOWN = 1, 2, 3, 4, 5, 6
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t

@@ -118,6 +118,7 @@ int kvc_set_option(int opt, int64_t value) {
   case KVC_OPT_POOL_BYTES: options().pool_bytes = value; break;
   case KVC_OPT_PROFILE: options().profile = value; break;
   case KVC_OPT_TLB_SHOOTDOWN: options().tlb_shootdown = value; break;
+  case KVC_OPT_DEFER_UNMAP_SHOOTDOWN: options().defer_unmap_shootdown = value; break;
   case 102: options().access_run_slots = value; break; // tuning only
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
@@ -135,6 +136,7 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_POOL_BYTES: return options().pool_bytes;
   case KVC_OPT_PROFILE: return options().profile;
   case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
+  case KVC_OPT_DEFER_UNMAP_SHOOTDOWN: return options().defer_unmap_shootdown;
   case 102: return options().access_run_slots;
   case 103: return options().zero_alias_fanout;
   case 105: return options().fill_chunk_slots;

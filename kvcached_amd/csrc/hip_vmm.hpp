@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <iterator>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -98,6 +99,9 @@ public:
   size_t granule() const { return granule_; }
   bool exportable() const { return exportable_; }
   void set_cap_bytes(size_t b) { cap_handles_ = b / granule_; }
+  // Called once before a batch of handles is given back to the driver (their physical memory leaves this
+  // process): the owner uses it to flush a TLB invalidation it had deferred.
+  void set_before_driver_release(std::function<void()> fn) { before_driver_release_ = std::move(fn); }
 
   // `recycled` tells the caller whether the memory may hold old data.
   Phys acquire(bool *recycled) {
@@ -178,6 +182,8 @@ public:
 
   // Release handles that never enter the pool (imports, teardown), oldest first.
   void to_driver(std::vector<Phys> &v) {
+    if (v.empty()) return;
+    if (before_driver_release_) before_driver_release_();
     std::sort(v.begin(), v.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; });
     for (auto &p : v) {
       hipError_t st = hipMemRelease(p.h);
@@ -193,6 +199,7 @@ private:
   bool exportable_;
   VmmCounters *ctr_;
   size_t cap_handles_ = 0;
+  std::function<void()> before_driver_release_;
   std::atomic<uint64_t> next_seq_{0};
   std::mutex mu_;
   std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle

@@ -99,7 +99,10 @@ PhysPool *GpuContext::pool(size_t granule, bool exportable) {
   std::lock_guard<std::mutex> g(mu_);
   auto &m = pools_[exportable ? 1 : 0];
   auto it = m.find(granule);
-  if (it == m.end()) it = m.emplace(granule, std::make_unique<PhysPool>(dev_, granule, exportable, &stats().vmm)).first;
+  if (it == m.end()) {
+    it = m.emplace(granule, std::make_unique<PhysPool>(dev_, granule, exportable, &stats().vmm)).first;
+    it->second->set_before_driver_release([this]() { flush_deferred_shootdown(); });
+  }
   it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   return it->second.get();
 }
@@ -299,6 +302,7 @@ int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, 
 }
 
 void GpuContext::tlb_shootdown() {
+  tlb_owed_.store(false);
   if (!options().tlb_shootdown.load()) return;
   const int64_t t0 = now_ns();
   void *p = nullptr;
@@ -351,6 +355,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
   options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 16384) << 20;
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
+  options().defer_unmap_shootdown = env_bool("KVCACHED_DEFER_UNMAP_SHOOTDOWN", false) ? 1 : 0;
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));
@@ -531,6 +536,13 @@ void KvAllocator::destroy_region(KvRegion &r) {
     r.mapped[i] = 0;
   }
   std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
+  if (ctx && !dead.empty()) { // this memory leaves the process: no translation to it may survive
+    try {
+      ctx->tlb_shootdown();
+    } catch (...) {
+      (void)hipGetLastError();
+    }
+  }
   for (auto &p : dead) {
     hipError_t st = hipMemRelease(p.h);
     if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease during cleanup failed: %s", hipGetErrorString(st));
@@ -831,7 +843,9 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
   };
   int64_t n_done = 0;
   std::vector<Phys> freed; // returned to the pool / driver in one batch, oldest first
+  std::vector<phys_handle_t> imported; // peers' pages: only our reference is dropped
   freed.reserve(slots.size());
+  bool any_backfilled = false;
   for (auto &s : slots) {
     KvRegion &r = *s.region;
     if (!r.mapped[s.index]) { // reference: log + skip (ftensor.cpp:124-127)
@@ -843,15 +857,14 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     HIP_CHECK(hipMemUnmap(va, ps));
     const int64_t t1 = now_ns();
     stats().t_unmap += t1 - t0;
-    if (r.mapped[s.index] == 1) {
+    if (r.mapped[s.index] == 1)
       freed.push_back(Phys{r.handle[s.index], r.seq[s.index]});
-    } else {
-      hipError_t st = hipMemRelease(r.handle[s.index]);
-      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
-    }
+    else
+      imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
     ++n_done;
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
+      any_backfilled = true;
       const int64_t tr = now_ns();
       HIP_CHECK(hipMemMap(va, ps, 0, r.zero_of(s.index), 0));
       stats().t_realias += now_ns() - tr;
@@ -863,9 +876,26 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
   }
   flush_run();
-  // stale entries would keep pointing at physical pages that now belong to the pool or to the driver:
-  // invalidate BEFORE the handles can be recycled or freed
-  if (n_done) ctx->tlb_shootdown();
+  // Stale TLB entries still translate the unmapped VAs to the old physical pages. Who can be hurt by them?
+  //   * a reader of the VA itself: only in compat mode is that legal (unbacked VA reads as zeros), so there the
+  //     invalidation happens now;
+  //   * the next owner of the physical page: if it stays in OUR pool, its next use is a map_slots() batch, which
+  //     invalidates before anything touches the page - the invalidation CAN wait for that (or for the moment the
+  //     pool gives handles back to the driver: PhysPool::set_before_driver_release). Optional and off by default
+  //     (KVC_OPT_DEFER_UNMAP_SHOOTDOWN): measured, the cost is conserved, not saved - the invalidation mostly waits
+  //     for the page-table updates the unmaps queued, so it only moves from free() into the next alloc()
+  //     (per page: unmap 354 -> 21 us, next map 205 -> 379 us; batches unchanged).
+  //   * memory leaving this process (imported pages, pool evictions): invalidate first.
+  if (n_done) {
+    if (any_backfilled || !imported.empty() || !options().defer_unmap_shootdown.load())
+      ctx->tlb_shootdown();
+    else
+      ctx->defer_tlb_shootdown();
+  }
+  for (auto h : imported) {
+    hipError_t st = hipMemRelease(h);
+    if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
+  }
   const int64_t tr0 = now_ns();
   pool->release_batch(freed.data(), freed.size());
   stats().t_release += now_ns() - tr0;

@@ -26,6 +26,7 @@ struct Options {
   std::atomic<int64_t> pool_bytes{16384ll << 20};
   std::atomic<int64_t> profile{0};
   std::atomic<int64_t> tlb_shootdown{1};
+  std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
   std::atomic<int64_t> fill_chunk_slots{1024}; // slots made usable (one TLB shootdown + fill launches) at a time
@@ -80,6 +81,11 @@ public:
   // on ROCm 7.2 (stale translations survive a remap: kvcached_amd/csrc/tools/remap_diag.cpp), but
   // the KFD map ioctl behind an ordinary >= 2 MiB hipMalloc does.
   void tlb_shootdown();
+  // unmap path: the invalidation is owed but nothing needs it yet (see KvAllocator::unmap_slots)
+  void defer_tlb_shootdown() { tlb_owed_.store(true); }
+  void flush_deferred_shootdown() {
+    if (tlb_owed_.load()) tlb_shootdown();
+  }
 
 private:
   struct Timed {
@@ -91,6 +97,7 @@ private:
   void harvest();
   int dev_;
   hipStream_t stream_ = nullptr;
+  std::atomic<bool> tlb_owed_{false};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];
   std::vector<Timed> inflight_;

@@ -128,6 +128,55 @@ def test_lazy_mode_without_backfill(vmm):
     assert ops.unmap_from_kv_tensors([2 * PAGE])
 
 
+def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
+    """KVC_OPT_DEFER_UNMAP_SHOOTDOWN in lazy mode: an unmap batch whose handles all return to the pool performs no
+    TLB invalidation of its own; the next map batch invalidates before anything touches
+    the recycled pages, and handles that leave the pool for the driver are preceded by one. Whatever the slot a
+    recycled (dirty) handle lands on, reads see zeros first and every page stays private."""
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=False, kv=1, unified=True)
+    assert capi.get_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN) == 0          # off by default
+    capi.set_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN, 1)
+    t = ts[0]
+    epp = PAGE // 2
+    import random
+    rng = random.Random(0)
+    live = {}
+    capi.reset_stats()
+    for r in range(8):
+        slots = rng.sample([s for s in range(32) if s not in live], rng.randint(3, 8))   # recycled handles, new slots
+        n0 = capi.get_stats()["tlb_shootdowns"]
+        assert ops.map_to_kv_tensors([s * PAGE for s in slots])
+        assert capi.get_stats()["tlb_shootdowns"] == n0 + 1
+        for s in slots:
+            page = t[s * epp:(s + 1) * epp]
+            assert int(torch.count_nonzero(page)) == 0, (r, s)          # recycled handles were dirty
+            page.fill_(100 * r + s + 1)
+            live[s] = 100 * r + s + 1
+        torch.cuda.synchronize()
+        for s, v in live.items():
+            assert bool((t[s * epp:(s + 1) * epp] == v).all()), (r, s)    # nobody else's write landed here
+        victims = slots[:len(slots) // 2 + 1]
+        n1 = capi.get_stats()["tlb_shootdowns"]
+        assert ops.unmap_from_kv_tensors([s * PAGE for s in victims])
+        assert capi.get_stats()["tlb_shootdowns"] == n1                  # deferred
+        for s in victims:
+            live.pop(s)
+    # the pool shrinks to nothing: the owed invalidation happens before the first handle goes to the driver
+    st0 = capi.get_stats()
+    capi.set_option(capi.OPT_POOL_BYTES, 0)
+    last = sorted(live)
+    assert ops.unmap_from_kv_tensors([s * PAGE for s in last])
+    st1 = capi.get_stats()
+    assert st1["handles_released"] > st0["handles_released"] and st1["tlb_shootdowns"] == st0["tlb_shootdowns"] + 1
+    # switched off, every unmap invalidates by itself
+    capi.set_option(capi.OPT_POOL_BYTES, 1 << 30)
+    capi.set_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN, 0)
+    assert ops.map_to_kv_tensors([5 * PAGE])
+    n = capi.get_stats()["tlb_shootdowns"]
+    assert ops.unmap_from_kv_tensors([5 * PAGE])
+    assert capi.get_stats()["tlb_shootdowns"] == n + 1
+
+
 def test_contiguous_layout_compound_pages(vmm):
     """One region for all layers; an offset backs page x layers x kv bytes in ONE mapping."""
     layers = 4

@@ -32,7 +32,8 @@ out["hbm_bytes_per_launch"] = out["write_bytes_per_launch"] + out["read_bytes_pe
 json.dump(out, open("profiles/zero_fill_traffic.json", "w"), indent=1)
 for src, dst in (("bench_elastic.log", f"{R}_bench_elastic.jsonl"), ("bench_tp_ipc.log", f"{R}_bench_tp_ipc.jsonl"),
                  ("create_diag.log", f"{R}_create_release_order.log"), ("compact_bench3.log", f"{R}_compact_bench.jsonl"),
-                 ("bench_n2_rehearsal.log", f"{R}_bench_n2_gloo_rehearsal.log"), ("pytest_gpu.log", f"{R}_pytest_gpu.log")):
+                 ("bench_n2_rehearsal.log", f"{R}_bench_n2_gloo_rehearsal.log"), ("pytest_gpu.log", f"{R}_pytest_gpu.log"),
+                 ("bench_vmm.log", f"{R}_bench_vmm.jsonl"), ("bench_sglang_glue.log", f"{R}_bench_sglang_glue.jsonl")):
     if os.path.exists("gpurun_out/" + src):
         shutil.copy("gpurun_out/" + src, "profiles/" + dst)
 print(open(f"profiles/{R}_rocprofv3_kernel_stats.csv").read())

@@ -30,3 +30,7 @@ echo "== elastic (config 3)"
 timeout -k 10 600 python benchmarks/bench_elastic.py 2>&1 | grep -v "amdgpu.ids\|IPC listener" > gpurun_out/bench_elastic.log; cut -c1-700 gpurun_out/bench_elastic.log
 echo "== tp ipc (config 4)"
 timeout -k 10 300 python benchmarks/bench_tp_ipc.py 2>&1 | grep -v "amdgpu.ids\|IPC listener" > gpurun_out/bench_tp_ipc.log; cut -c1-400 gpurun_out/bench_tp_ipc.log
+echo "== bench_vmm (config 2 in full)"
+timeout -k 10 600 python benchmarks/bench_vmm.py 2>&1 | grep -v "amdgpu.ids" > gpurun_out/bench_vmm.log; cut -c1-900 gpurun_out/bench_vmm.log
+echo "== sglang glue"
+timeout -k 10 300 python benchmarks/bench_sglang_glue.py 2>&1 | grep -v "amdgpu.ids" > gpurun_out/bench_sglang_glue.log; tail -3 gpurun_out/bench_sglang_glue.log | cut -c1-300
