@@ -122,6 +122,7 @@ int kvc_set_option(int opt, int64_t value) {
   case 102: options().access_run_slots = value; break; // tuning only
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
+  case 107: options().pool_idle_ms = value < 0 ? 0 : value; break;
   case 104: fail_after_creates() = value; break;       // fault injection: the (value+1)-th hipMemCreate fails
   case 100: options().fill_variant = value; break;    // tuning only
   case 101: options().compact_variant = value; break; // tuning only
@@ -140,6 +141,7 @@ int64_t kvc_get_option(int opt) {
   case 102: return options().access_run_slots;
   case 103: return options().zero_alias_fanout;
   case 105: return options().fill_chunk_slots;
+  case 107: return options().pool_idle_ms;
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;

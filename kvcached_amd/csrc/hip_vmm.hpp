@@ -111,6 +111,7 @@ public:
         auto it = std::prev(idle_.end()); // youngest: the old ones stay cheap to give back
         Phys p{it->second, it->first};
         idle_.erase(it);
+        low_water_ = std::min(low_water_, idle_.size());
         ctr_->reused++;
         *recycled = true;
         return p;
@@ -162,6 +163,39 @@ public:
     to_driver(victims);
   }
 
+  // Idle-time decay (called from the allocator's 10 Hz watcher): the handles nobody needed during a whole
+  // window of `idle_ns` - the low-water mark of the idle set over that window - go back to the driver, at
+  // most `max_release` per call. The pool is a recycling buffer for alloc/free churn, not a place to keep
+  // memory: a co-located engine computes what it may use from hipMemGetInfo and would never see what is
+  // parked here (the reference releases on every unmap, csrc/page.cpp:17).
+  size_t decay(int64_t now_ns, int64_t idle_ns, size_t max_release) {
+    std::vector<Phys> victims;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (window_start_ns_ == 0 || idle_.empty()) {
+        window_start_ns_ = now_ns;
+        low_water_ = idle_.size();
+        return 0;
+      }
+      if (now_ns - window_start_ns_ < idle_ns) return 0;
+      const size_t surplus = std::min(low_water_, idle_.size());
+      const size_t n = std::min(surplus, max_release);
+      for (size_t i = 0; i < n; ++i) {
+        auto it = idle_.begin();
+        victims.push_back(Phys{it->second, it->first});
+        idle_.erase(it);
+      }
+      if (n < surplus) {
+        low_water_ = surplus - n; // keep going at the next tick
+      } else {
+        window_start_ns_ = now_ns;
+        low_water_ = idle_.size();
+      }
+    }
+    to_driver(victims);
+    return victims.size();
+  }
+
   // hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release batch.
   bool under_pressure() const {
     size_t free_b = 0, total_b = 0;
@@ -203,6 +237,8 @@ private:
   std::atomic<uint64_t> next_seq_{0};
   std::mutex mu_;
   std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle
+  size_t low_water_ = 0;                         // smallest idle_ size since window_start_ns_
+  int64_t window_start_ns_ = 0;
 };
 
 inline void *vmm_reserve(size_t size, size_t align, void *hint) {

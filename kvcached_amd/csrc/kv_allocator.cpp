@@ -117,7 +117,7 @@ void GpuContext::drain_pools() {
   for (auto *p : ps) p->drain(0);
 }
 
-void GpuContext::relieve_pressure() {
+void GpuContext::housekeeping() {
   std::vector<PhysPool *> ps;
   {
     std::lock_guard<std::mutex> g(mu_);
@@ -126,8 +126,13 @@ void GpuContext::relieve_pressure() {
   }
   if (ps.empty()) return;
   (void)hipSetDevice(dev_);
-  if (ps[0]->under_pressure())
+  if (ps[0]->under_pressure()) {
     for (auto *p : ps) p->drain(0);
+    return;
+  }
+  const int64_t idle_ms = options().pool_idle_ms.load();
+  if (idle_ms > 0)
+    for (auto *p : ps) p->decay(now_ns(), idle_ms * 1000000ll, 1024);
 }
 
 void GpuContext::begin_timed(hipStream_t s, int kind) {
@@ -356,6 +361,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 16384) << 20;
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
   options().defer_unmap_shootdown = env_bool("KVCACHED_DEFER_UNMAP_SHOOTDOWN", false) ? 1 : 0;
+  options().pool_idle_ms = std::max<int64_t>(0, env_i64("KVCACHED_POOL_IDLE_MS", 1000));
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));

@@ -26,6 +26,7 @@ struct Options {
   std::atomic<int64_t> pool_bytes{16384ll << 20};
   std::atomic<int64_t> profile{0};
   std::atomic<int64_t> tlb_shootdown{1};
+  std::atomic<int64_t> pool_idle_ms{1000};       // idle handles older than this are released (0 = keep until pressure)
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
@@ -61,7 +62,9 @@ public:
   hipStream_t stream() const { return stream_; }
   PhysPool *pool(size_t granule, bool exportable);
   void drain_pools();
-  void relieve_pressure(); // drain idle handles if the device is short of free memory (10 Hz from the watcher)
+  // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
+  // let handles that sat idle for KVCACHED_POOL_IDLE_MS go back to the driver (PhysPool::decay)
+  void housekeeping();
 
   // kernel launches on `s` (NULL = own stream), timed with events when profiling is on
   void zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s);

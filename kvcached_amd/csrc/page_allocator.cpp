@@ -437,7 +437,7 @@ void PageAllocator::resize_watcher() { // :764-778 (100 ms poll; NB compares wit
     watcher_cv_.wait_for(lk, std::chrono::milliseconds(100), [&] { return !watcher_running_; });
     if (!watcher_running_) break;
     tracker_->revalidate();
-    if (GpuContext *ctx = KvAllocator::gpu()) ctx->relieve_pressure(); // idle pooled handles must not starve a neighbour
+    if (GpuContext *ctx = KvAllocator::gpu()) ctx->housekeeping(); // idle pooled handles must not starve a neighbour
     resize_target_.store(tracker_->check_and_get_resize_target(mem_size_per_layer_, num_layers_, num_kv_buffers_),
                          std::memory_order_relaxed);
   }
