@@ -349,7 +349,8 @@ def main():
     fanout = barrier = None
     sync = torch.cuda.synchronize
     backend = os.environ.get("KVC_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N>1 code path on one GPU
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("KVC_BENCH_FORCE_DIST") == "1"   # forced: rehearse the N>1 path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -362,7 +363,7 @@ def main():
 
     res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync)
     elapsed = res["elapsed"]
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -388,7 +389,7 @@ def main():
                                    "pages (shuffled offsets), both halves timed",
                        "mode": args.mode, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
-                       "fanout": f"{backend} broadcast + all-reduce(min)" if world > 1 else "local"},
+                       "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
             "map_zero_GBps": round(main_sum["map_zero_GBps"], 2),
             "p50_map_batch_ms": round(main_sum["p50_map_batch_ms"], 3),
             "p90_map_batch_ms": round(main_sum["p90_map_batch_ms"], 3),
@@ -430,7 +431,7 @@ def main():
                 line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)
                 line["reference_hip_path_growth_burst"] = reference_on_box(24, 4, burst=True)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
