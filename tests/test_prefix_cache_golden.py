@@ -112,3 +112,17 @@ def test_pool_over_the_real_manager(monkeypatch):
     finally:
         vmm_ops.shutdown_kvcached()
         capi.set_mem_info_override(0, 0)
+
+
+# ---- make_cache_key: the reference's tests/test_make_cache_key.py restated against our function
+def _gid(group_id: int) -> bytes:
+    return group_id.to_bytes(4, "big", signed=False)
+
+
+@pytest.mark.parametrize("group_id", [0, 1, 255, 256, 65535, 2 ** 31 - 1])
+def test_make_cache_key_encoding(group_id):
+    from kvcached_amd.integration.vllm.block_pool import make_cache_key
+    assert make_cache_key(b"h", group_id) == b"h" + _gid(group_id)
+    assert make_cache_key("deadbeef", group_id) == make_cache_key(b"deadbeef", group_id) == b"deadbeef" + _gid(group_id)
+    make_cache_key("0a1b2c3d" * 8, 0)                      # a 64-char hex digest (str) must not raise
+    assert make_cache_key(b"samehash", 0) != make_cache_key(b"samehash", 1)
