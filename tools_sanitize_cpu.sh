@@ -1,0 +1,20 @@
+#!/bin/bash
+# Host-side sanitizer passes over the library (GPU ASAN/XNACK are not available on the pool: CPU build only).
+# Builds libkvcached_amd.so with -Xarch_host -fsanitize=<address|thread>, swaps it in for the in-tree library,
+# runs the CPU test suite under the matching runtime, and restores the normal build.
+# usage: ./tools_sanitize_cpu.sh address|thread
+set -e
+SAN=${1:-address}
+RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.$([ "$SAN" = address ] && echo asan || echo tsan)-x86_64.so
+cd "$(dirname "$0")"
+mkdir -p build/$SAN
+(cd kvcached_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -pthread \
+    -Xarch_host -fsanitize=$SAN -Xarch_host -fno-omit-frame-pointer -x hip \
+    c_api.cpp kv_allocator.cpp page_allocator.cpp kernels.hip index_kernels.hip -o ../../build/$SAN/libkvcached_amd.so)
+cp kvcached_amd/libkvcached_amd.so build/libkvcached_amd.so.bak
+restore() { cp build/libkvcached_amd.so.bak kvcached_amd/libkvcached_amd.so; sleep 1; touch kvcached_amd/vmm_ops.*.so; }
+trap restore EXIT
+cp build/$SAN/libkvcached_amd.so kvcached_amd/libkvcached_amd.so; sleep 1; touch kvcached_amd/vmm_ops.*.so
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" \
+    python -m pytest tests -q -m "not gpu" -p no:cacheprovider 2>&1 | tee build/$SAN/run.log | tail -3
+echo "sanitizer reports: $(grep -c 'ERROR: AddressSanitizer\|WARNING: ThreadSanitizer' build/$SAN/run.log)"
