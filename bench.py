@@ -221,7 +221,7 @@ def compaction_roofline(capi, device):
         st = capi.get_stats()
         capi.set_option(capi.OPT_PROFILE, 0)
         achieved = st["compact_bytes"] / (st["compact_ms"] * 1e-3) / 1e9
-        return {"kernel": "compact_blocks (LDS-staged, XCD-aware)", "bound": "hbm", "achieved": round(achieved, 1),
+        return {"kernel": "compact_blocks (LDS-staged, XCD-aware, non-temporal)", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
                 "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""compact_blocks micro-benchmark on one MI355X: kernel variants x geometries, timed with HIP events inside the
+library. `--profile-shape` runs ONE geometry/variant a few times and nothing else, for rocprofv3 passes
+(kernel trace, and FETCH_SIZE / WRITE_SIZE each in its own --pmc pass) whose per-launch HBM traffic is compared
+with the algorithmic bytes: read = written = block_bytes x regions x moves per launch."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+KiB = 1 << 10
+VARIANTS = ["lds+xcd+nt (default)", "reg+xcd+nt", "lds", "reg", "lds+xcd", "reg+xcd"]
+GEOMETRIES = ((32 * KiB, 64, 4096, 2048),     # Llama-3-8B: 32 layers x K/V regions, 32 KiB blocks
+              (32 * KiB, 64, 4096, 256),
+              (16 * KiB, 32, 8192, 2048),     # cfg 1 of the reference's tests: 16 layers, 16 KiB blocks
+              (18432, 54, 4096, 1024))        # MLA-like: 16 tokens x 1152 B, 27 layers x 2
+
+
+def setup(block, regions, n_blocks, moves):
+    import numpy as np
+    import torch
+    bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device="cuda:0") for _ in range(regions)]
+    ids = np.random.default_rng(0).permutation(n_blocks)[:2 * moves]
+    src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
+    torch.cuda.synchronize()
+    return bufs, [b.data_ptr() for b in bufs], src, dst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--profile-shape", action="store_true", help="Llama-3-8B geometry, default variant, 6 calls, no sweep")
+    args = ap.parse_args()
+    os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU")
+    from kvcached_amd import capi
+    capi.init("cuda:0", 2 << 20, False)
+    try:
+        if args.profile_shape:
+            block, regions, n_blocks, moves = GEOMETRIES[0]
+            bufs, bases, src, dst = setup(block, regions, n_blocks, moves)
+            for _ in range(6):
+                capi.compact_blocks(bases, src, dst, block)
+            print(json.dumps({"block": block, "regions": regions, "moves": moves,
+                              "algorithmic_read_bytes_per_call": block * regions * moves,
+                              "algorithmic_write_bytes_per_call": block * regions * moves}))
+            return
+        for block, regions, n_blocks, moves in GEOMETRIES:
+            bufs, bases, src, dst = setup(block, regions, n_blocks, moves)
+            for variant in range(len(VARIANTS)):
+                capi.set_option(capi.OPT_COMPACT_VARIANT, variant)
+                for _ in range(2):
+                    capi.compact_blocks(bases, src, dst, block)
+                capi.set_option(capi.OPT_PROFILE, 1)
+                capi.reset_stats()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    capi.compact_blocks(bases, src, dst, block, sync=False)
+                capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
+                wall = time.perf_counter() - t0
+                st = capi.get_stats()
+                capi.set_option(capi.OPT_PROFILE, 0)
+                print(json.dumps(dict(block=block, regions=regions, moves=moves, variant=VARIANTS[variant],
+                                      launches=st["compact_launches"], event_GBps=round(st["compact_bytes"] / st["compact_ms"] / 1e6),
+                                      wall_GBps=round(st["compact_bytes"] / wall / 1e9))), flush=True)
+            capi.set_option(capi.OPT_COMPACT_VARIANT, 0)
+            del bufs
+    finally:
+        capi.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,7 +130,7 @@ __device__ __forceinline__ bool compact_index(unsigned n_moves, unsigned n_regio
 // for its own DMAs (vmcnt), reads them back with ds_read_b128 and streams them out with
 // global_store_dwordx4. A wave only ever reads LDS bytes it loaded itself, so no barrier is
 // needed; 16 KiB of LDS per workgroup lets 8+ workgroups share a CU (>=128 KiB in flight).
-template <bool XCD>
+template <bool XCD, bool NT>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(CompactArgs a, unsigned n_moves,
                                                                               unsigned n_regions,
                                                                               unsigned tiles_per_block,
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(Com
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                        (__attribute__((address_space(3))) void *)(tile +
                                                                                   (wave * kPiecesPerWave + i) * kPiece),
-                                       16, 0, 0);
+                                       16, 0, NT ? 2 : 0); // aux bit 1 = nt on gfx94x/gfx950
   }
   // The DMA writes LDS behind the compiler's back: wait for this wave's pieces by hand.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -161,8 +161,13 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(Com
     for (int i = 0; i < kPiecesPerWave; ++i)
       v[i] = *reinterpret_cast<const v4u *>(tile + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
 #pragma unroll
-    for (int i = 0; i < kPiecesPerWave; ++i)
-      *reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16) = v[i];
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      v4u *o = reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+      if (NT)
+        __builtin_nontemporal_store(v[i], o);
+      else
+        *o = v[i];
+    }
   } else {
     for (int i = 0; i < kPiecesPerWave; ++i) {
       const unsigned off = (wave * kPiecesPerWave + i) * kPiece + lane * 16;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_lds_kernel(Com
 }
 
 // Variant 1 — register-staged: all loads of a lane in flight first, then the stores.
-template <bool XCD>
+template <bool XCD, bool NT>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(CompactArgs a, unsigned n_moves,
                                                                               unsigned n_regions,
                                                                               unsigned tiles_per_block,
@@ -186,11 +191,18 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(Com
   if (remain >= (unsigned)kCompactTile) { // full tile: every load in flight before the first store
     v4u v[kPiecesPerWave];
 #pragma unroll
-    for (int i = 0; i < kPiecesPerWave; ++i)
-      v[i] = *reinterpret_cast<const v4u *>(src + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      const v4u *in = reinterpret_cast<const v4u *>(src + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+      v[i] = NT ? __builtin_nontemporal_load(in) : *in;
+    }
 #pragma unroll
-    for (int i = 0; i < kPiecesPerWave; ++i)
-      *reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16) = v[i];
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      v4u *o = reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWave + i) * kPiece + lane * 16);
+      if (NT)
+        __builtin_nontemporal_store(v[i], o);
+      else
+        *o = v[i];
+    }
   } else {
     for (int i = 0; i < kPiecesPerWave; ++i) {
       const unsigned off = (wave * kPiecesPerWave + i) * kPiece + lane * 16;
@@ -221,18 +233,27 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
   if (grid_xcd > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 blk(kCompactThreads);
   const unsigned nm = (unsigned)n_moves, nr = (unsigned)n_regions, bb = (unsigned)block_bytes;
+  // Non-temporal loads and stores are the default: every byte is touched exactly once, and keeping it out of the
+  // way of the L2/MALL is worth +2..7 % (profiles/r01_compact_bench.jsonl; same on a plain contiguous copy,
+  // tools/copy_bench.cpp: 5.9 vs 5.66 TB/s).
   switch (variant) {
-  case 1: // register-staged, XCD-aware
-    compact_blocks_reg_kernel<true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+  case 1: // register-staged, XCD-aware, non-temporal
+    compact_blocks_reg_kernel<true, true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
     break;
-  case 2: // LDS-staged, interleaved (pre-XCD-aware mapping, for A/B runs)
-    compact_blocks_lds_kernel<false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+  case 2: // LDS-staged, interleaved placement, temporal (the first version; A/B runs)
+    compact_blocks_lds_kernel<false, false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
     break;
-  case 3: // register-staged, interleaved
-    compact_blocks_reg_kernel<false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+  case 3: // register-staged, interleaved, temporal
+    compact_blocks_reg_kernel<false, false><<<dim3((unsigned)grid), blk, 0, stream>>>(a, nm, nr, tiles, bb);
     break;
-  default: // LDS-staged, XCD-aware
-    compact_blocks_lds_kernel<true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+  case 4: // LDS-staged, XCD-aware, temporal
+    compact_blocks_lds_kernel<true, false><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+    break;
+  case 5: // register-staged, XCD-aware, temporal
+    compact_blocks_reg_kernel<true, false><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
+    break;
+  default: // LDS-staged, XCD-aware, non-temporal
+    compact_blocks_lds_kernel<true, true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
   }
   return hipGetLastError();
 }

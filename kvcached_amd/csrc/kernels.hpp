@@ -24,8 +24,9 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
 // Copy blocks inside each region: for r < n_regions, m < n_moves:
 //   bases[r] + dst[m]*block_bytes  <-  bases[r] + src[m]*block_bytes
 // n_regions <= kMaxRegionsPerLaunch, n_moves <= kMaxMovesPerLaunch. variant 0 = LDS-staged
-// (LDS-DMA in, ds_read_b128 + global_store out) with XCD-aware block placement, 1 = register-staged
-// XCD-aware, 2/3 = the same two with the plain interleaved placement (A/B runs).
+// (LDS-DMA in, ds_read_b128 + global_store out), XCD-aware block placement, non-temporal accesses; 1 = the same
+// register-staged; 2/3 = LDS/register-staged with the plain interleaved placement and temporal accesses;
+// 4/5 = LDS/register-staged XCD-aware with temporal accesses (A/B runs).
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant = 0);
 

@@ -36,5 +36,31 @@ for src, dst in (("bench_elastic.log", f"{R}_bench_elastic.jsonl"), ("bench_tp_i
                  ("bench_vmm.log", f"{R}_bench_vmm.jsonl"), ("bench_sglang_glue.log", f"{R}_bench_sglang_glue.jsonl")):
     if os.path.exists("gpurun_out/" + src):
         shutil.copy("gpurun_out/" + src, "profiles/" + dst)
+# ---- compact_blocks (benchmarks/bench_compact.py --profile-shape under rocprofv3, build/prof_compact.sh)
+ckt = newest("gpurun_out/prof_compact_kt/runc/*_kernel_trace.csv")
+if ckt:
+    from collections import defaultdict
+    dur, wr, rd_ = defaultdict(list), defaultdict(list), defaultdict(list)
+    for r in csv.DictReader(open(ckt)):
+        if "compact_blocks" in r["Kernel_Name"]:
+            dur[r["Grid_Size_X"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for path, name, dst in (("gpurun_out/prof_compact_w/runc/*_counter_collection.csv", "WRITE_SIZE", wr),
+                            ("gpurun_out/prof_compact_r/runc/*_counter_collection.csv", "FETCH_SIZE", rd_)):
+        for r in csv.DictReader(open(newest(path))):
+            if r["Counter_Name"] == name and "compact_blocks" in r["Kernel_Name"]:
+                dst[r["Grid_Size"]].append(float(r["Counter_Value"]))
+    shapes = []
+    for grid, d in dur.items():
+        moves = int(grid) // 256 // 2 // 64          # grid = moves x 64 regions x 2 tiles (32 KiB block / 16 KiB tile) x 256 threads
+        algo = 32768 * 64 * moves
+        w, f = int(statistics.mean(wr[grid]) * 1024), int(2 * statistics.mean(rd_[grid]) * 1024)
+        shapes.append({"moves": moves, "launches": len(d), "avg_us": round(sum(d) / len(d), 1),
+                       "algorithmic_read_bytes": algo, "algorithmic_write_bytes": algo, "pmc_write_bytes": w, "pmc_read_bytes": f,
+                       "traffic_over_algorithmic": round((w + f) / (2 * algo), 4),
+                       "GBps_read_plus_write": round(2 * algo / (sum(d) / len(d)) / 1e3, 1)})
+    json.dump({"kernel": "kvc::compact_blocks_lds_kernel<true>", "geometry": "Llama-3-8B: 64 regions x 32 KiB blocks",
+               "note": "rocprofv3 --kernel-trace for durations; WRITE_SIZE and FETCH_SIZE in separate --pmc passes; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B)",
+               "per_launch": shapes}, open(f"profiles/{R}_compact_traffic.json", "w"), indent=1)
+    shutil.copy(newest("gpurun_out/prof_compact_kt/runc/*_kernel_stats.csv"), f"profiles/{R}_rocprofv3_compact_kernel_stats.csv")
 print(open(f"profiles/{R}_rocprofv3_kernel_stats.csv").read())
 print(json.dumps(out["rocprofv3_kernel_trace"]), json.dumps(out["bench_hip_events"]))
