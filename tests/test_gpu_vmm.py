@@ -230,6 +230,50 @@ def test_large_batch_random_order(vmm):
     assert capi.get_stats()["pages_unmapped"] == 2048
 
 
+def test_full_bench_window_64GiB_size_independent_properties(vmm):
+    """BASELINE configs[1] at its full size: a 64 GiB window, all 32 768 x 2 MiB slots backed in shuffled 1024-page
+    batches (lazy mode, like the bench). Properties that do not depend on the size: (1) every freshly backed byte reads
+    zero; (2) a per-page stamp survives until that page is unmapped and no stamp leaks into another page — checked
+    with per-page sums; (3) re-backing half of the slots in a different order (recycled, dirty handles) gives zeros
+    again and leaves the other half's stamps intact; (4) the driver-handle ledger balances."""
+    import numpy as np
+    n_pages = 32768
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=n_pages * PAGE, backfill=False, kv=1, unified=True)
+    t = ts[0]                                                   # int16 elements
+    epp = PAGE // 2
+    rng = np.random.default_rng(0)
+    order = rng.permutation(n_pages)
+    capi.reset_stats()
+    for b in range(0, n_pages, 1024):
+        assert ops.map_to_kv_tensors([int(p) * PAGE for p in order[b:b + 1024]])
+    st = capi.get_stats()
+    assert st["pages_mapped"] == n_pages and st["fill_bytes"] == n_pages * PAGE
+    v = t.view(n_pages, epp)
+    assert all(int(torch.count_nonzero(v[i:i + 1024])) == 0 for i in range(0, n_pages, 1024))   # (1), in 2 GiB pieces
+    stamp = (torch.arange(n_pages, device=DEV) % 251 + 1).to(torch.int16)
+    v.copy_(stamp.unsqueeze(1).expand_as(v))
+    torch.cuda.synchronize()
+
+    def page_sums():
+        return torch.cat([v[i:i + 1024].sum(dim=1, dtype=torch.int32) for i in range(0, n_pages, 1024)])
+    assert torch.equal(page_sums(), stamp.to(torch.int32) * epp)                              # (2)
+    victims = rng.permutation(n_pages)[: n_pages // 2]
+    for b in range(0, len(victims), 1024):
+        assert ops.unmap_from_kv_tensors([int(p) * PAGE for p in victims[b:b + 1024]])
+    back = rng.permutation(victims)
+    for b in range(0, len(back), 1024):
+        assert ops.map_to_kv_tensors([int(p) * PAGE for p in back[b:b + 1024]])
+    want = stamp.to(torch.int32) * epp
+    want[torch.as_tensor(victims, device=DEV)] = 0
+    assert torch.equal(page_sums(), want)                                                     # (3)
+    for b in range(0, n_pages, 4096):
+        assert ops.unmap_from_kv_tensors([int(p) * PAGE for p in range(b, b + 4096)])
+    st = capi.get_stats()
+    assert st["pages_mapped"] == n_pages + len(victims) == st["pages_unmapped"]
+    assert st["handles_created"] + st["handles_reused"] == st["pages_mapped"]                 # (4)
+    assert st["handles_reused"] >= len(victims) // 2
+
+
 def test_mem_get_info_and_avail_physical_pages(vmm):
     ops, capi, ts = _setup(vmm)
     free, total = capi.mem_get_info()
