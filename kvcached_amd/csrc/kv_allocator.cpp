@@ -117,6 +117,14 @@ void GpuContext::drain_pools() {
   for (auto *p : ps) p->drain(0);
 }
 
+size_t GpuContext::idle_pool_bytes() {
+  std::lock_guard<std::mutex> g(mu_);
+  size_t b = 0;
+  for (auto &m : pools_)
+    for (auto &kv : m) b += kv.second->idle_count() * kv.second->granule();
+  return b;
+}
+
 void GpuContext::housekeeping() {
   std::vector<PhysPool *> ps;
   {
@@ -430,6 +438,9 @@ void mem_get_info(size_t *free_b, size_t *total_b) {
   if (!ctx) throw NoGpuError("hipMemGetInfo needs a GPU device (init_kvcached with \"cuda:N\"), or a mem-info override");
   ctx->bind();
   HIP_CHECK(hipMemGetInfo(free_b, total_b));
+  // What sits idle in our own handle pool is as good as free for this allocator (the reference would have
+  // released it, csrc/page.cpp:17): without this, alloc() right after a large free() could be refused.
+  *free_b = std::min(*total_b, *free_b + ctx->idle_pool_bytes());
 }
 void set_mem_info_override(size_t free_b, size_t total_b) {
   g_override_free = free_b;

@@ -62,6 +62,7 @@ public:
   hipStream_t stream() const { return stream_; }
   PhysPool *pool(size_t granule, bool exportable);
   void drain_pools();
+  size_t idle_pool_bytes(); // physical memory parked in the handle pools: ours to reuse, invisible to hipMemGetInfo
   // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
   // let handles that sat idle for KVCACHED_POOL_IDLE_MS go back to the driver (PhysPool::decay)
   void housekeeping();

@@ -80,6 +80,7 @@ def _wait_for(fn, pred, timeout):
 def test_two_engines_share_one_gpu():
     ctx = mp.get_context("spawn")
     pipes, procs = [], []
+    ballast = None
     for name in ("kvc_colo_a", "kvc_colo_b"):
         parent, child = ctx.Pipe()
         p = ctx.Process(target=_engine, args=(f"{name}_{os.getpid()}", child), daemon=True)
@@ -107,6 +108,10 @@ def test_two_engines_share_one_gpu():
         # A finishes: its pages are unmapped and the handles parked in A's pool; within the idle window + a few
         # watcher ticks they are back with the driver and B can have them
         assert _ask(a, "free")
+        # ... and are A's own to take back at once: its available_size counts what sits in its pool
+        assert _ask(a, "avail") >= a0 - BLOCKS_PER_GIB
+        assert _ask(a, "alloc", 6 * BLOCKS_PER_GIB) == 6 * BLOCKS_PER_GIB
+        assert _ask(a, "free")
         b2, took = _wait_for(lambda: _ask(b, "avail"), lambda v: v >= b0 - BLOCKS_PER_GIB, timeout=10)
         assert took is not None, f"B still sees {b2} blocks (started with {b0}) 10 s after A freed 6 GiB"
         sa = _ask(a, "stats")
@@ -120,10 +125,11 @@ def test_two_engines_share_one_gpu():
         both, took2 = _wait_for(lambda: min(_ask(a, "avail"), _ask(b, "avail")), lambda v: v >= a0 - BLOCKS_PER_GIB, timeout=10)
         assert took2 is not None, both
         print(f"[colocation] reclaim after free: {took:.2f} s (idle window 0.5 s), second round {took2:.2f} s")
-        del ballast
         for c in pipes:
             assert _ask(c, "quit")
     finally:
+        ballast = None
+        torch.cuda.empty_cache()          # give the ballast back to the driver: later tests need the memory
         for p in procs:
             p.join(10)
             if p.is_alive():
