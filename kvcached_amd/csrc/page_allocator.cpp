@@ -177,6 +177,15 @@ void PageAllocator::free_pages(const page_id_t *page_ids, size_t n) { // :264-31
 bool PageAllocator::resize(int64_t new_mem_size) { // :312-401
   const int64_t new_pages = new_mem_size / page_size_;
   std::vector<page_id_t> to_unmap;
+  // A smaller budget means "give memory back now" (kvctl limit): what the handle pool holds goes too, without
+  // waiting for its idle decay. Done on scope exit, i.e. after lock_ is released.
+  struct DrainOnShrink {
+    bool armed = false;
+    ~DrainOnShrink() {
+      if (armed)
+        if (GpuContext *ctx = KvAllocator::gpu()) ctx->drain_pools();
+    }
+  } drain;
   {
     std::lock_guard<std::mutex> g(lock_);
     const int64_t total = num_total_pages_.load();
@@ -204,6 +213,7 @@ bool PageAllocator::resize(int64_t new_mem_size) { // :312-401
       }
       num_free_pages_ -= shrink;
       num_total_pages_ = new_pages;
+      drain.armed = true;
       return true;
     }
     if (reserved_list_.empty()) return false;
@@ -211,6 +221,7 @@ bool PageAllocator::resize(int64_t new_mem_size) { // :312-401
     reserved_list_.clear();
   }
   unmap_pages(to_unmap.data(), to_unmap.size());
+  drain.armed = true;
   std::lock_guard<std::mutex> g(lock_);
   const int64_t shrink = num_total_pages_.load() - new_pages;
   free_list_.insert(free_list_.end(), to_unmap.begin(), to_unmap.end());

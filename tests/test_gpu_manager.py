@@ -314,3 +314,32 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
     finally:
         capi.set_option(104, -1)
         vmm_ops.shutdown_kvcached()
+
+
+def test_shrinking_the_budget_releases_pooled_handles(monkeypatch):
+    """`kvctl limit` semantics: a successful shrink gives memory back now — what the handle pool parked goes to the
+    driver at once instead of waiting for the idle decay (the reference releases on every unmap)."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    try:
+        vmm_ops.create_kv_tensors(32 * T.PAGE * 2, 1, DEV, 2, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=32 * 64, block_size=16, cell_size=2048, num_layers=2)
+        assert m._post_init_done.wait(10)
+        ids = m.alloc(20 * 64)                                   # 20 page ids = 80 slots
+        capi.reset_stats()
+        m.free(ids)                                              # 10 stay reserved (mapped), 10 are unmapped -> pool
+        st = capi.get_stats()
+        assert st["pages_unmapped"] == 40 and st["handles_released"] == 0
+        free0, _ = capi.mem_get_info()
+        assert m.page_allocator.resize(24 * T.PAGE)              # 32 -> 24 page ids: plain free-list shrink
+        st = capi.get_stats()
+        assert st["handles_released"] == 40                      # the pooled handles went back to the driver
+        assert m.page_allocator.get_num_total_pages() == 24
+        assert m.page_allocator.resize(32 * T.PAGE)
+        got = m.alloc(64)
+        m.free(got)
+        del m
+    finally:
+        vmm_ops.shutdown_kvcached()
