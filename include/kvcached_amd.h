@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KVC_ABI_VERSION 2
+#define KVC_ABI_VERSION 3
 
 enum {
   KVC_OK = 0,
@@ -87,11 +87,19 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              before it touches anything) or for the moment handles are given back to the
  *                              driver, whichever comes first; 0 (default) = invalidate inside every unmap call
  *                              (the cost only moves from free() to the next alloc()).
- *                              Compat mode (ZERO_BACKFILL) and imported pages always invalidate at once. */
+ *                              Compat mode (ZERO_BACKFILL) and imported pages always invalidate at once.
+ *   KVC_OPT_ASYNC_UNMAP    1 = kvc_unmap_from_kv_tensors only marks the slots and queues them; a reclaimer thread
+ *                              of the library carries out hipMemUnmap + invalidation + handle recycling in small
+ *                              chunks, yielding to map calls. A slot that is mapped again before its turn is kept
+ *                              as it is (no driver call, zero-filled again). The caller's free() path drops from
+ *                              ~15 us per slot to a queue push; queued bytes count as free in kvc_mem_get_info.
+ *                              kvc_flush_unmaps() waits for the queue (trim/resize/shutdown do it themselves).
+ *                              0 (default) = synchronous, like the reference. Ignored in compat mode. */
 enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
-       KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6 };
+       KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6, KVC_OPT_ASYNC_UNMAP = 7 };
 int kvc_set_option(int opt, int64_t value);
 int64_t kvc_get_option(int opt);
+int kvc_flush_unmaps(void); /* wait until every queued (async) unmap has been carried out */
 
 /* Counters since kvc_init / last reset. */
 typedef struct kvc_stats {
@@ -106,6 +114,7 @@ typedef struct kvc_stats {
   int64_t tlb_shootdowns;                     /* explicit GPU TLB invalidations (see KVC_OPT_TLB_SHOOTDOWN) */
   int64_t shootdown_ns;                       /* host wall time spent in them */
   int64_t index_launches;                     /* block id <-> token index kernels (kvc_expand_block_ids ...) */
+  int64_t unmaps_queued, unmaps_cancelled;    /* async unmap: slots queued / mapped again before the reclaimer's turn */
 } kvc_stats_t;
 int kvc_get_stats(kvc_stats_t *out);
 int kvc_reset_stats(void);

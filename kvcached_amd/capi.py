@@ -23,6 +23,7 @@ lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, KVC_E_CALLBACK = 0, -1, -2, -3, -4, -5, -6
 KVC_E_NOT_CREATED = -7
 OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN, OPT_DEFER_UNMAP_SHOOTDOWN = 1, 2, 3, 4, 5, 6
+OPT_ASYNC_UNMAP = 7
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
@@ -41,7 +42,8 @@ class Stats(ctypes.Structure):
                 ("map_calls", _i64), ("unmap_calls", _i64), ("map_ns", _i64), ("unmap_ns", _i64),
                 ("fill_launches", _i64), ("fill_bytes", _i64), ("fill_ms", ctypes.c_double),
                 ("compact_launches", _i64), ("compact_bytes", _i64), ("compact_ms", ctypes.c_double),
-                ("tlb_shootdowns", _i64), ("shootdown_ns", _i64), ("index_launches", _i64)]
+                ("tlb_shootdowns", _i64), ("shootdown_ns", _i64), ("index_launches", _i64),
+                ("unmaps_queued", _i64), ("unmaps_cancelled", _i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -62,6 +64,7 @@ SIGNATURES = {
     "kvc_get_option": (_i64, [_int]),
     "kvc_get_stats": (_int, [ctypes.POINTER(Stats)]),
     "kvc_reset_stats": (_int, []),
+    "kvc_flush_unmaps": (_int, []),
     "kvc_get_driver_breakdown": (_int, [_I64P]),
     "kvc_mem_get_info": (_int, [_SZP, _SZP]),
     "kvc_set_mem_info_override": (_int, [_sz, _sz]),
@@ -191,6 +194,10 @@ def get_driver_breakdown() -> dict:
     out = (ctypes.c_int64 * 8)()
     check(lib.kvc_get_driver_breakdown(out))
     return dict(zip(DRIVER_CALLS, (int(x) for x in out)))
+
+
+def flush_unmaps() -> None:
+    check(lib.kvc_flush_unmaps())
 
 
 def reset_stats() -> None:

@@ -119,6 +119,10 @@ int kvc_set_option(int opt, int64_t value) {
   case KVC_OPT_PROFILE: options().profile = value; break;
   case KVC_OPT_TLB_SHOOTDOWN: options().tlb_shootdown = value; break;
   case KVC_OPT_DEFER_UNMAP_SHOOTDOWN: options().defer_unmap_shootdown = value; break;
+  case KVC_OPT_ASYNC_UNMAP:
+    if (!value) KvAllocator::flush_all_unmaps(); // switching off: nothing may stay queued
+    options().async_unmap = value;
+    break;
   case 102: options().access_run_slots = value; break; // tuning only
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
@@ -138,6 +142,7 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_PROFILE: return options().profile;
   case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
   case KVC_OPT_DEFER_UNMAP_SHOOTDOWN: return options().defer_unmap_shootdown;
+  case KVC_OPT_ASYNC_UNMAP: return options().async_unmap;
   case 102: return options().access_run_slots;
   case 103: return options().zero_alias_fanout;
   case 105: return options().fill_chunk_slots;
@@ -168,10 +173,18 @@ int kvc_get_stats(kvc_stats_t *o) {
   o->tlb_shootdowns = s.tlb_shootdowns;
   o->shootdown_ns = s.shootdown_ns;
   o->index_launches = s.index_launches;
+  o->unmaps_queued = s.unmaps_queued;
+  o->unmaps_cancelled = s.unmaps_cancelled;
   std::lock_guard<std::mutex> g(s.mu);
   o->fill_ms = s.fill_ms;
   o->compact_ms = s.compact_ms;
   return KVC_OK;
+}
+int kvc_flush_unmaps(void) {
+  return guarded([&]() -> int {
+    KvAllocator::flush_all_unmaps();
+    return KVC_OK;
+  });
 }
 int kvc_get_driver_breakdown(int64_t *o) {
   if (!o) return fail(KVC_E_INVALID, "NULL output");

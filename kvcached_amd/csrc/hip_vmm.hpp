@@ -103,6 +103,18 @@ public:
   // process): the owner uses it to flush a TLB invalidation it had deferred.
   void set_before_driver_release(std::function<void()> fn) { before_driver_release_ = std::move(fn); }
 
+  // An idle handle if there is one (never creates).
+  bool try_acquire_idle(Phys *out) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (idle_.empty()) return false;
+    auto it = std::prev(idle_.end());
+    *out = Phys{it->second, it->first};
+    idle_.erase(it);
+    low_water_ = std::min(low_water_, idle_.size());
+    ctr_->reused++;
+    return true;
+  }
+
   // `recycled` tells the caller whether the memory may hold old data.
   Phys acquire(bool *recycled) {
     {

@@ -27,6 +27,7 @@ void Stats::reset() {
   fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
   tlb_shootdowns = shootdown_ns = 0;
   index_launches = 0;
+  unmaps_queued = unmaps_cancelled = 0;
   t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
   vmm.created = vmm.released = vmm.reused = 0;
   std::lock_guard<std::mutex> g(mu);
@@ -43,6 +44,7 @@ bool g_initialized = false;
 size_t g_page_size = kBasePage;
 std::atomic<size_t> g_vaddr_offset{0}; // running offset behind kStartAddr (reference: ftensor.cpp:17)
 std::atomic<size_t> g_override_free{0}, g_override_total{0};
+std::atomic<size_t> g_pending_unmap_bytes{0}; // async unmap: released by the caller, not yet by the driver
 
 int resolve_dev_index(const DeviceSpec &d) {
   if (d.index >= 0) return d.index;
@@ -370,6 +372,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
   options().defer_unmap_shootdown = env_bool("KVCACHED_DEFER_UNMAP_SHOOTDOWN", false) ? 1 : 0;
   options().pool_idle_ms = std::max<int64_t>(0, env_i64("KVCACHED_POOL_IDLE_MS", 1000));
+  options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));
@@ -440,7 +443,7 @@ void mem_get_info(size_t *free_b, size_t *total_b) {
   HIP_CHECK(hipMemGetInfo(free_b, total_b));
   // What sits idle in our own handle pool is as good as free for this allocator (the reference would have
   // released it, csrc/page.cpp:17): without this, alloc() right after a large free() could be refused.
-  *free_b = std::min(*total_b, *free_b + ctx->idle_pool_bytes());
+  *free_b = std::min(*total_b, *free_b + ctx->idle_pool_bytes() + g_pending_unmap_bytes.load());
 }
 void set_mem_info_override(size_t free_b, size_t total_b) {
   g_override_free = free_b;
@@ -460,10 +463,99 @@ KvAllocator::KvAllocator(DeviceSpec dev, bool contiguous_layout, GpuContext *ctx
 }
 
 KvAllocator::~KvAllocator() {
+  if (reclaimer_.joinable()) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      reclaimer_stop_ = true;
+    }
+    pending_cv_.notify_all();
+    reclaimer_.join();
+  }
   std::lock_guard<std::mutex> g(mu_);
-  for (auto &r : layers_) destroy_region(*r);
+  size_t still_queued = 0;
+  for (auto &r : layers_) {
+    for (auto m : r->mapped) still_queued += (m == 3) ? r->page_size : 0;
+    destroy_region(*r); // also unmaps what was still queued (state 3 counts as mapped there)
+  }
+  g_pending_unmap_bytes -= std::min(still_queued, g_pending_unmap_bytes.load());
   layers_.clear();
 }
+
+// ------------------------------------------------------------------ async unmap
+// With KVC_OPT_ASYNC_UNMAP the caller's free() path only marks slots and queues them; this thread carries out the
+// driver calls (hipMemUnmap is 15 us per slot, 1 ms for one page id of the Llama-3-8B geometry - time the
+// scheduler thread of an engine would otherwise spend blocked). Bookkeeping stays synchronous, so page ids and
+// block tables are unaffected. A slot that is backed again before its turn is simply kept (no driver call at
+// all, just the zero fill). The driver serialises page-table updates per process, so this buys latency, not
+// throughput: the reclaimer works in small chunks and yields to foreground map calls.
+void KvAllocator::lock_foreground(std::unique_lock<std::mutex> &lk) {
+  foreground_waiting_.fetch_add(1);
+  lk.lock();
+  foreground_waiting_.fetch_sub(1);
+}
+
+void KvAllocator::reclaimer_loop() {
+  constexpr size_t kChunk = 128; // slots per critical section: <= 2 ms of driver calls between two chances to yield
+  if (ctx_) {
+    try {
+      ctx_->bind();
+    } catch (...) {
+    }
+  }
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    pending_cv_.wait(lk, [&] { return reclaimer_stop_ || !pending_.empty(); });
+    if (reclaimer_stop_) return;
+    std::vector<Slot> chunk;
+    while (!pending_.empty() && chunk.size() < kChunk) {
+      Slot s = pending_.front();
+      pending_.pop_front();
+      if (s.region->mapped[s.index] == 3) { // still released (not re-backed, not already handled via a duplicate entry)
+        s.region->mapped[s.index] = 1;
+        chunk.push_back(s);
+      }
+    }
+    if (chunk.empty()) {
+      if (pending_.empty()) drained_cv_.notify_all();
+      continue;
+    }
+    reclaimer_busy_ = true;
+    Unmapped u;
+    try {
+      unmap_collect(chunk, u);
+    } catch (const std::exception &e) {
+      KVC_LOG(LOG_ERROR, "async unmap failed: %s", e.what());
+    }
+    g_pending_unmap_bytes -= std::min(chunk.size() * chunk[0].region->page_size, g_pending_unmap_bytes.load());
+    lk.unlock();
+    try {
+      unmap_finish(u, false); // TLB invalidation + handles back to the pool: no allocator state involved
+    } catch (const std::exception &e) {
+      KVC_LOG(LOG_ERROR, "async unmap (finish) failed: %s", e.what());
+    }
+    while (foreground_waiting_.load() > 0) std::this_thread::yield(); // map calls go first
+    lk.lock();
+    reclaimer_busy_ = false;
+    if (pending_.empty()) drained_cv_.notify_all();
+  }
+}
+
+void KvAllocator::flush_unmaps() {
+  std::unique_lock<std::mutex> lk(mu_);
+  if (!reclaimer_.joinable()) return;
+  drained_cv_.wait(lk, [&] { return pending_.empty() && !reclaimer_busy_; });
+}
+
+void KvAllocator::flush_all_unmaps() {
+  std::vector<KvAllocator *> all;
+  {
+    std::lock_guard<std::mutex> g(g_mu);
+    for (auto &kv : g_allocators) all.push_back(kv.second.get());
+  }
+  for (auto *a : all) a->flush_unmaps();
+}
+
+size_t KvAllocator::pending_unmap_bytes() { return g_pending_unmap_bytes.load(); }
 
 std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size_t size, size_t page_size) {
   if (size % kBasePage != 0) throw InvalidError("alloc size not aligned.");
@@ -676,7 +768,8 @@ std::vector<KvAllocator::Slot> KvAllocator::slots_for(const offset_t *offsets, s
 
 bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
   const int64_t t0 = now_ns();
-  std::lock_guard<std::mutex> g(mu_);
+  std::unique_lock<std::mutex> g(mu_, std::defer_lock);
+  lock_foreground(g);
   if (num_layers_ == 0) {
     KVC_LOG(LOG_ERROR, "try to map to KV tensors when KV tensors are not created");
     return false;
@@ -689,15 +782,65 @@ bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
 
 bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
   const int64_t t0 = now_ns();
-  std::lock_guard<std::mutex> g(mu_);
+  std::unique_lock<std::mutex> g(mu_, std::defer_lock);
+  lock_foreground(g);
   if (num_layers_ == 0) {
     KVC_LOG(LOG_ERROR, "try to unmap from KV tensors when KV tensors are not created");
     return false;
   }
-  unmap_slots(slots_for(offsets, n));
+  auto slots = slots_for(offsets, n);
+  bool async = options().async_unmap.load() && dev_.is_gpu;
+  for (auto &r : layers_) async = async && !r->backfilled; // compat mode promises zeros behind an unmap: stay synchronous
+  if (async) {
+    std::vector<Slot> now; // imported pages are a peer's memory: dropped at once
+    size_t queued = 0;
+    for (auto &s : slots) {
+      uint8_t &m = s.region->mapped[s.index];
+      if (m == 1) {
+        m = 3;
+        pending_.push_back(s);
+        ++queued;
+      } else if (m == 2) {
+        now.push_back(s);
+      } else { // reference: log + skip (ftensor.cpp:124-127)
+        KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", s.index);
+      }
+    }
+    if (queued) {
+      g_pending_unmap_bytes += queued * slots[0].region->page_size;
+      stats().unmaps_queued += (int64_t)queued;
+      if (!reclaimer_.joinable()) reclaimer_ = std::thread(&KvAllocator::reclaimer_loop, this);
+      pending_cv_.notify_one();
+    }
+    if (!now.empty()) unmap_slots(now);
+  } else {
+    unmap_slots(slots);
+  }
   stats().unmap_calls++;
   stats().unmap_ns += now_ns() - t0;
   return true;
+}
+
+// Async unmap, map side: when the pool has nothing idle, the page of a slot that is released but not yet
+// unmapped is the cheapest handle there is (one hipMemUnmap, which was owed anyway) - and the handle population
+// stays what it would be with synchronous unmaps instead of growing by hipMemCreate (O(live handles)). Needs mu_.
+// The stale translation of the victim's VA is covered by the caller's TLB invalidation (before its fill).
+bool KvAllocator::steal_pending(size_t ps, Phys *out) {
+  while (!pending_.empty()) {
+    Slot s = pending_.front();
+    pending_.pop_front();
+    KvRegion &r = *s.region;
+    if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
+    const int64_t t0 = now_ns();
+    HIP_CHECK(hipMemUnmap(r.base + s.index * ps, ps));
+    stats().t_unmap += now_ns() - t0;
+    r.mapped[s.index] = 0;
+    *out = Phys{r.handle[s.index], r.seq[s.index]};
+    g_pending_unmap_bytes -= std::min(ps, g_pending_unmap_bytes.load());
+    stats().pages_unmapped++;
+    return true;
+  }
+  return false;
 }
 
 // The hot loop. Per slot: [unmap the zero alias] -> pooled handle -> hipMemMap; per contiguous run: one
@@ -765,9 +908,18 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     run_len = 0;
   };
 
+  std::vector<Slot> kept; // async unmap: released but not yet unmapped -> simply kept, only zero-filled again
   try {
     for (auto &s : slots) {
       KvRegion &r = *s.region;
+      if (r.mapped[s.index] == 3 && !imported) {
+        r.mapped[s.index] = 1; // its queue entry is dropped by the reclaimer (state no longer 3)
+        kept.push_back(s);
+        g_pending_unmap_bytes -= std::min(ps, g_pending_unmap_bytes.load());
+        stats().unmaps_cancelled++;
+        if (fill) pending.push_back(r.base + s.index * ps);
+        continue;
+      }
       if (r.mapped[s.index]) { // reference: log + skip, the batch still succeeds (ftensor.cpp:104-107)
         KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", s.index);
         if (imported) ++next_import;
@@ -778,7 +930,17 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (r.backfilled) HIP_CHECK(hipMemUnmap(va, ps));
       int64_t t1 = now_ns();
       bool recycled = false;
-      Phys ph = imported ? Phys{(*imported)[next_import++], 0} : pool->acquire(&recycled);
+      Phys ph;
+      if (imported) {
+        ph = Phys{(*imported)[next_import++], 0};
+      } else if (pool->try_acquire_idle(&ph)) {
+        recycled = true;
+      } else if (steal_pending(ps, &ph)) { // async unmap: take the page of a released slot instead of creating one
+        recycled = true;
+        dirty_tlb = true;
+      } else {
+        ph = pool->acquire(&recycled);
+      }
       phys_handle_t h = ph.h;
       int64_t t2 = now_ns();
       hipError_t st = hipMemMap(va, ps, 0, h, 0);
@@ -811,6 +973,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   } catch (...) {
     // leave the regions as they were before this call; PageAllocator rolls the page ids back
     if (launched) (void)hipStreamSynchronize(ctx->stream());
+    for (auto &k : kept) { // still in the reclaimer's queue: just hand them back to it
+      k.region->mapped[k.index] = 3;
+      g_pending_unmap_bytes += ps;
+    }
     for (auto it = done.rbegin(); it != done.rend(); ++it) {
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
@@ -829,7 +995,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     }
     throw;
   }
-  stats().pages_mapped += (int64_t)done.size();
+  stats().pages_mapped += (int64_t)(done.size() + kept.size());
 }
 
 void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
@@ -845,10 +1011,17 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
     return;
   }
+  Unmapped u;
+  unmap_collect(slots, u);
+  unmap_finish(u, true);
+}
+
+// Driver unmaps (and, in compat mode, the re-aliasing) of `slots`; the handles are only collected. Needs mu_.
+void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   GpuContext *ctx = ctx_;
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
-  PhysPool *pool = ctx->pool(ps, exportable_);
+  u.page_size = ps;
   const auto acc = make_rw_access(ctx->dev());
   char *run_start = nullptr;
   size_t run_len = 0;
@@ -858,14 +1031,10 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
     run_len = 0;
   };
-  int64_t n_done = 0;
-  std::vector<Phys> freed; // returned to the pool / driver in one batch, oldest first
-  std::vector<phys_handle_t> imported; // peers' pages: only our reference is dropped
-  freed.reserve(slots.size());
-  bool any_backfilled = false;
+  u.own.reserve(slots.size());
   for (auto &s : slots) {
     KvRegion &r = *s.region;
-    if (!r.mapped[s.index]) { // reference: log + skip (ftensor.cpp:124-127)
+    if (r.mapped[s.index] != 1 && r.mapped[s.index] != 2) { // reference: log + skip (ftensor.cpp:124-127)
       KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", s.index);
       continue;
     }
@@ -875,13 +1044,13 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     const int64_t t1 = now_ns();
     stats().t_unmap += t1 - t0;
     if (r.mapped[s.index] == 1)
-      freed.push_back(Phys{r.handle[s.index], r.seq[s.index]});
+      u.own.push_back(Phys{r.handle[s.index], r.seq[s.index]});
     else
-      imported.push_back(r.handle[s.index]);
+      u.imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
-    ++n_done;
+    ++u.n;
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
-      any_backfilled = true;
+      u.any_backfilled = true;
       const int64_t tr = now_ns();
       HIP_CHECK(hipMemMap(va, ps, 0, r.zero_of(s.index), 0));
       stats().t_realias += now_ns() - tr;
@@ -893,6 +1062,14 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
     }
   }
   flush_run();
+}
+
+// TLB invalidation, then the handles go back to the pool / the driver. Touches no allocator state (the async
+// reclaimer calls it without mu_).
+void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
+  if (!u.n) return;
+  GpuContext *ctx = ctx_;
+  PhysPool *pool = ctx->pool(u.page_size, exportable_);
   // Stale TLB entries still translate the unmapped VAs to the old physical pages. Who can be hurt by them?
   //   * a reader of the VA itself: only in compat mode is that legal (unbacked VA reads as zeros), so there the
   //     invalidation happens now;
@@ -903,20 +1080,18 @@ void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
   //     for the page-table updates the unmaps queued, so it only moves from free() into the next alloc()
   //     (per page: unmap 354 -> 21 us, next map 205 -> 379 us; batches unchanged).
   //   * memory leaving this process (imported pages, pool evictions): invalidate first.
-  if (n_done) {
-    if (any_backfilled || !imported.empty() || !options().defer_unmap_shootdown.load())
-      ctx->tlb_shootdown();
-    else
-      ctx->defer_tlb_shootdown();
-  }
-  for (auto h : imported) {
+  if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !options().defer_unmap_shootdown.load())
+    ctx->tlb_shootdown();
+  else
+    ctx->defer_tlb_shootdown();
+  for (auto h : u.imported) {
     hipError_t st = hipMemRelease(h);
     if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
   }
   const int64_t tr0 = now_ns();
-  pool->release_batch(freed.data(), freed.size());
+  pool->release_batch(u.own.data(), u.own.size());
   stats().t_release += now_ns() - tr0;
-  stats().pages_unmapped += n_done;
+  stats().pages_unmapped += u.n;
 }
 
 // ------------------------------------------------------------------ TP shared pool

@@ -9,8 +9,11 @@
 // instead of aborting the process.
 #pragma once
 
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -27,6 +30,7 @@ struct Options {
   std::atomic<int64_t> profile{0};
   std::atomic<int64_t> tlb_shootdown{1};
   std::atomic<int64_t> pool_idle_ms{1000};       // idle handles older than this are released (0 = keep until pressure)
+  std::atomic<int64_t> async_unmap{0};           // unmap_from_kv_tensors only queues; a reclaimer thread does the driver calls
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
@@ -43,6 +47,7 @@ struct Stats {
   std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
   std::atomic<int64_t> tlb_shootdowns{0}, shootdown_ns{0};
   std::atomic<int64_t> index_launches{0};
+  std::atomic<int64_t> unmaps_queued{0}, unmaps_cancelled{0}; // async unmap: slots queued / re-backed before the reclaimer got to them
   // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
   std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
   std::mutex mu;
@@ -129,7 +134,8 @@ struct KvRegion {
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
-  std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page
+  std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
+                                       // 3 = released by the caller, physical unmap still queued (async unmap)
   size_t num_slots() const { return size / page_size; }
 };
 
@@ -158,6 +164,12 @@ public:
   bool unmap_from_kv_tensors(const offset_t *offsets, size_t n);
   std::vector<void *> region_bases(); // layer-major, K then V (compact_blocks' region table)
 
+  // async unmap (KVC_OPT_ASYNC_UNMAP): wait until every queued unmap of this allocator / of all allocators has
+  // been carried out; bytes still queued (they count as free for this process)
+  void flush_unmaps();
+  static void flush_all_unmaps();
+  static size_t pending_unmap_bytes();
+
   // TP shared pool
   int export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap);
   bool map_imported_slots(const offset_t *offsets, size_t n, const int *fds, size_t n_fds);
@@ -173,6 +185,19 @@ private:
   void backfill_all(KvRegion &r);
   void map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported);
   void unmap_slots(const std::vector<Slot> &slots);
+  // the two halves of unmap_slots: driver unmaps under mu_ (handles collected), then invalidate + give handles back
+  struct Unmapped {
+    std::vector<Phys> own;
+    std::vector<phys_handle_t> imported;
+    bool any_backfilled = false;
+    int64_t n = 0;
+    size_t page_size = 0;
+  };
+  void unmap_collect(const std::vector<Slot> &slots, Unmapped &out);
+  void unmap_finish(Unmapped &u, bool may_defer_shootdown);
+  void reclaimer_loop();
+  bool steal_pending(size_t page_size, Phys *out);
+  void lock_foreground(std::unique_lock<std::mutex> &lk); // mu_ with priority over the reclaimer
 
   DeviceSpec dev_;
   bool contiguous_;
@@ -184,6 +209,12 @@ private:
   size_t tensor_bytes_per_layer_ = 0;
   std::mutex mu_;
   std::vector<std::unique_ptr<KvRegion>> layers_; // per-layer regions, or ONE region in contiguous layout
+  // async unmap state (guarded by mu_)
+  std::deque<Slot> pending_;
+  std::condition_variable pending_cv_, drained_cv_;
+  std::thread reclaimer_;
+  bool reclaimer_stop_ = false, reclaimer_busy_ = false;
+  std::atomic<int> foreground_waiting_{0};
 };
 
 // hipMemGetInfo of the init device, or the test override.

@@ -182,8 +182,9 @@ bool PageAllocator::resize(int64_t new_mem_size) { // :312-401
   struct DrainOnShrink {
     bool armed = false;
     ~DrainOnShrink() {
-      if (armed)
-        if (GpuContext *ctx = KvAllocator::gpu()) ctx->drain_pools();
+      if (!armed) return;
+      KvAllocator::flush_all_unmaps(); // queued (async) unmaps first: their handles are part of what goes back
+      if (GpuContext *ctx = KvAllocator::gpu()) ctx->drain_pools();
     }
   } drain;
   {
@@ -252,7 +253,8 @@ void PageAllocator::trim() { // :403-427
     free_list_.insert(free_list_.end(), to_unmap.begin(), to_unmap.end());
     publish_usage();
   }
-  // trim() means "give physical memory back": idle pooled handles count as well
+  // trim() means "give physical memory back": queued (async) unmaps and idle pooled handles count as well
+  KvAllocator::flush_all_unmaps();
   if (GpuContext *ctx = KvAllocator::gpu()) ctx->drain_pools();
 }
 

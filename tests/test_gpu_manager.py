@@ -343,3 +343,31 @@ def test_shrinking_the_budget_releases_pooled_handles(monkeypatch):
         del m
     finally:
         vmm_ops.shutdown_kvcached()
+
+
+def test_golden_trace_with_async_unmap(monkeypatch):
+    """Bookkeeping is synchronous, so the reference's golden trace (block ids, page offsets, counters) is still
+    bit-exact with KVC_OPT_ASYNC_UNMAP on; after a flush the physical ledger matches the synchronous run."""
+    from kvcached_amd import capi
+    case = load("manager_large.json")["cases"][2]
+    os.environ["KVCACHED_ASYNC_UNMAP"] = "true"
+    try:
+        ad = _gpu_adapter(case["config"])
+    finally:
+        os.environ.pop("KVCACHED_ASYNC_UNMAP", None)
+    try:
+        assert capi.get_option(capi.OPT_ASYNC_UNMAP) == 1
+        init = {"s": ad.snapshot(), "e": ad.drain_events()}
+        assert init == case["init"]
+        capi.reset_stats()
+        got = T.replay(ad, case["ops"], full=False)
+        chain = T.chain_hash(got)
+        assert chain["checkpoints"] == case["chain"]["checkpoints"] and chain["final"] == case["chain"]["final"]
+        capi.flush_unmaps()
+        st = capi.get_stats()
+        assert st["unmaps_queued"] > 0
+        assert st["pages_unmapped"] + st["unmaps_cancelled"] == st["unmaps_queued"]
+        assert st["pages_mapped"] - st["pages_unmapped"] - st["unmaps_cancelled"] >= 0
+    finally:
+        ad.close()
+        capi.set_option(capi.OPT_ASYNC_UNMAP, 0)

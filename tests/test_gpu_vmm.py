@@ -25,6 +25,7 @@ def vmm():
     vmm_ops.shutdown_kvcached()
     capi.set_option(capi.OPT_ZERO_BACKFILL, 1)
     capi.set_option(capi.OPT_ZERO_FILL, 1)
+    capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
 
 
 def _setup(vmm, layers=2, per_layer=64 * MiB, contiguous=False, backfill=True, kv=2, unified=False):
@@ -175,6 +176,55 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     n = capi.get_stats()["tlb_shootdowns"]
     assert ops.unmap_from_kv_tensors([5 * PAGE])
     assert capi.get_stats()["tlb_shootdowns"] == n + 1
+
+
+def test_async_unmap_queue_reclaimer_and_rebacking(vmm):
+    """KVC_OPT_ASYNC_UNMAP: unmap_from_kv_tensors returns after queueing; the reclaimer thread does the driver calls.
+    Queued bytes count as free; a slot mapped again before its turn is kept as it is (no driver call) and reads
+    zero again; everything else is unmapped for real (flush) and can be backed afresh; the handle ledger balances."""
+    import time
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=8192 * MiB, backfill=False, kv=1, unified=True)
+    capi.set_option(capi.OPT_ASYNC_UNMAP, 1)
+    t = ts[0]
+    epp = PAGE // 2
+    n = 2048                                                     # 4 GiB: ~30 ms of driver unmaps
+    offs = [i * PAGE for i in range(n)]
+    assert ops.map_to_kv_tensors(offs)
+    v = t[:n * epp].view(n, epp)
+    v.copy_((torch.arange(n, device=DEV) % 200 + 1).to(torch.int16).unsqueeze(1).expand_as(v))
+    torch.cuda.synchronize()
+    free_before, _ = capi.mem_get_info()
+    capi.reset_stats()
+    t0 = time.perf_counter()
+    assert ops.unmap_from_kv_tensors(offs)
+    dt_queue = time.perf_counter() - t0
+    free_after, _ = capi.mem_get_info()
+    st = capi.get_stats()
+    assert st["unmaps_queued"] == n and st["unmap_calls"] == 1
+    assert dt_queue < 0.010, dt_queue                            # the synchronous path needs ~30 ms for this batch
+    assert free_after >= free_before + (n - 300) * PAGE          # queued or already pooled: ours either way
+    # the tail of the queue is mapped again at once: kept, not re-created, zero-filled
+    tail = offs[-64:]
+    assert ops.map_to_kv_tensors(tail)
+    st = capi.get_stats()
+    assert st["unmaps_cancelled"] == 64 and st["handles_created"] == 0 and st["handles_reused"] == 0
+    assert int(torch.count_nonzero(v[-64:])) == 0
+    v[-64:].fill_(7)
+    capi.flush_unmaps()
+    st = capi.get_stats()
+    assert st["pages_unmapped"] == n - 64
+    torch.cuda.synchronize()
+    assert bool((v[-64:] == 7).all())                            # the kept pages were not touched by the reclaimer
+    # a double unmap of a queued/unmapped slot is tolerated like the reference's (log + skip)
+    assert ops.unmap_from_kv_tensors(offs[:4])
+    # back everything again: recycled handles, zeros, private
+    assert ops.map_to_kv_tensors(offs[:-64])
+    assert all(int(torch.count_nonzero(v[i:min(i + 512, n - 64)])) == 0 for i in range(0, n - 64, 512))
+    assert ops.unmap_from_kv_tensors(offs)
+    capi.flush_unmaps()
+    st = capi.get_stats()
+    assert st["pages_unmapped"] == 2 * n - 64 and st["pages_mapped"] == n
+    capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
 
 
 def test_contiguous_layout_compound_pages(vmm):
