@@ -522,14 +522,19 @@ void KvAllocator::reclaimer_loop() {
     reclaimer_busy_ = true;
     Unmapped u;
     try {
-      unmap_collect(chunk, u);
+      if (dev_.is_gpu) {
+        unmap_collect(chunk, u);
+      } else {
+        for (auto &c : chunk) c.region->mapped[c.index] = 0;
+        stats().pages_unmapped += (int64_t)chunk.size();
+      }
     } catch (const std::exception &e) {
       KVC_LOG(LOG_ERROR, "async unmap failed: %s", e.what());
     }
     g_pending_unmap_bytes -= std::min(chunk.size() * chunk[0].region->page_size, g_pending_unmap_bytes.load());
     lk.unlock();
     try {
-      unmap_finish(u, false); // TLB invalidation + handles back to the pool: no allocator state involved
+      if (dev_.is_gpu) unmap_finish(u, false); // TLB invalidation + handles back to the pool: no allocator state involved
     } catch (const std::exception &e) {
       KVC_LOG(LOG_ERROR, "async unmap (finish) failed: %s", e.what());
     }
@@ -789,7 +794,7 @@ bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
     return false;
   }
   auto slots = slots_for(offsets, n);
-  bool async = options().async_unmap.load() && dev_.is_gpu;
+  bool async = options().async_unmap.load() != 0; // also on the cpu device: same queue and thread, no driver calls
   for (auto &r : layers_) async = async && !r->backfilled; // compat mode promises zeros behind an unmap: stay synchronous
   if (async) {
     std::vector<Slot> now; // imported pages are a peer's memory: dropped at once
@@ -850,6 +855,13 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   if (slots.empty()) return;
   if (!dev_.is_gpu) { // reference CPUPage::map is a no-op (page.cpp:34-37); keep the double-map diagnostics
     for (auto &s : slots) {
+      if (s.region->mapped[s.index] == 3) { // async unmap: released, not yet reclaimed -> kept
+        s.region->mapped[s.index] = 1;
+        g_pending_unmap_bytes -= std::min(s.region->page_size, g_pending_unmap_bytes.load());
+        stats().unmaps_cancelled++;
+        stats().pages_mapped++;
+        continue;
+      }
       if (s.region->mapped[s.index]) {
         KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", s.index);
         continue;

@@ -274,3 +274,42 @@ def test_compaction_planner(cpu_ops):
         m.compact()
     assert m.page_allocator.get_num_inuse_pages() == before_inuse
     del m
+
+
+def test_async_unmap_queue_on_the_cpu_device(cpu_ops):
+    """KVC_OPT_ASYNC_UNMAP's queue/reclaimer/re-backing logic without a GPU (the cpu device has no driver calls, the
+    state machine and the threads are the same): several threads map and unmap disjoint slot ranges while the
+    reclaimer drains; after a flush the ledger balances. Run under TSAN by tools_sanitize_cpu.sh."""
+    ops, capi = cpu_ops
+    ops.create_kv_tensors(512 * PAGE * 2, 1, "cpu", 2, 2, 0, False)
+    capi.set_option(capi.OPT_ASYNC_UNMAP, 1)
+    try:
+        capi.reset_stats()
+        errors = []
+
+        def churn(base):
+            try:
+                offs = [(base + i) * PAGE for i in range(64)]
+                for r in range(40):
+                    assert ops.map_to_kv_tensors(offs)
+                    assert ops.unmap_from_kv_tensors(offs[r % 7:])
+                    assert ops.unmap_from_kv_tensors(offs[:r % 7])
+            except Exception as e:  # surfaced below
+                errors.append(e)
+        ts = [threading.Thread(target=churn, args=(b,)) for b in (0, 64, 128, 192)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+        capi.flush_unmaps()
+        st = capi.get_stats()
+        slots = 4 * 40 * 64 * 4                                   # threads x rounds x offsets x (2 layers x K/V)
+        assert st["pages_mapped"] == slots and st["unmaps_queued"] == slots
+        assert st["pages_unmapped"] + st["unmaps_cancelled"] == slots
+        # everything is unbacked now: mapping again works, and switching the option off flushes by itself
+        assert ops.map_to_kv_tensors([0, PAGE]) and ops.unmap_from_kv_tensors([0, PAGE])
+        capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
+        assert capi.get_stats()["pages_unmapped"] + capi.get_stats()["unmaps_cancelled"] == slots + 8
+    finally:
+        capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
