@@ -55,7 +55,7 @@ __device__ __forceinline__ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 
 
 // ---------------------------------------------------------------------------- expand_block_ids
 // out[i*tpb + j] = ids[i]*tpb + j        (patches.py:192-196: page_ids[:, None] * page_size + arange)
-__global__ __launch_bounds__(256) void expand_block_ids_kernel(IdTable tbl, const int64_t *ids_dev, size_t n_ids,
+__global__ __launch_bounds__(256) void expand_block_ids_kernel([[maybe_unused]] IdTable tbl, const int64_t *ids_dev, size_t n_ids,
                                                                 unsigned tpb, int64_t *out) {
   const int64_t *ids = id_array(ids_dev);
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void expand_block_ids_kernel(IdTable tbl, cons
 // request order. (Same result as SGLang's alloc_extend_kernel, restated position by position.)
 static constexpr int kExtendTokensPerGroup = 4096;
 
-__global__ __launch_bounds__(256) void alloc_extend_kernel(IdTable tbl, const int64_t *ids_dev, size_t n_ids,
+__global__ __launch_bounds__(256) void alloc_extend_kernel([[maybe_unused]] IdTable tbl, const int64_t *ids_dev, size_t n_ids,
                                                             const int64_t *__restrict__ pre_lens,
                                                             const int64_t *__restrict__ seq_lens,
                                                             const int64_t *__restrict__ last_loc, int64_t tpb,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void alloc_extend_kernel(IdTable tbl, const in
 // ---------------------------------------------------------------------------- alloc_decode_indices
 // One new token per request (seq_len already counts it): it opens a new block iff (seq_len-1) is a
 // multiple of tpb, else it follows last_loc. New blocks are consumed in request order.
-__global__ __launch_bounds__(256) void alloc_decode_kernel(IdTable tbl, const int64_t *ids_dev, size_t n_ids,
+__global__ __launch_bounds__(256) void alloc_decode_kernel([[maybe_unused]] IdTable tbl, const int64_t *ids_dev, size_t n_ids,
                                                             const int64_t *__restrict__ seq_lens,
                                                             const int64_t *__restrict__ last_loc, unsigned bs, int64_t tpb,
                                                             int64_t *__restrict__ out) {

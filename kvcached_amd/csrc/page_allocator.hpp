@@ -105,7 +105,9 @@ private:
   bool use_broadcast() const;
   void stop_threads();
 
-  const int64_t num_layers_, mem_size_per_layer_, page_size_, world_size_, pp_rank_, num_kv_buffers_, group_id_;
+  const int64_t num_layers_, mem_size_per_layer_, page_size_, world_size_;
+  [[maybe_unused]] const int64_t pp_rank_; // carried for the broadcast callbacks' owner (tp_ipc_util picks the sockets by it)
+  const int64_t num_kv_buffers_, group_id_;
   const bool async_sched_, contiguous_layout_, enable_page_prealloc_;
   const double gpu_utilization_;
 
