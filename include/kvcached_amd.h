@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KVC_ABI_VERSION 3
+#define KVC_ABI_VERSION 4
 
 enum {
   KVC_OK = 0,
@@ -161,6 +161,9 @@ void kvc_pa_delete(kvc_page_allocator_t *pa);
 int kvc_pa_start_prealloc_thread(kvc_page_allocator_t *pa);
 int kvc_pa_stop_prealloc_thread(kvc_page_allocator_t *pa);
 int64_t kvc_pa_alloc_page(kvc_page_allocator_t *pa); /* page id, or KVC_E_* */
+/* Addition: the ids n alloc_page() calls would return, with ONE map call for those that need backing;
+ * all-or-nothing. Returns n (ids in out_ids[n]) or KVC_E_*. */
+int64_t kvc_pa_alloc_pages(kvc_page_allocator_t *pa, int64_t n, int64_t *out_ids);
 int kvc_pa_free_page(kvc_page_allocator_t *pa, int64_t page_id);
 int kvc_pa_free_pages(kvc_page_allocator_t *pa, const int64_t *page_ids, size_t n);
 int kvc_pa_resize(kvc_page_allocator_t *pa, int64_t new_mem_size); /* 1 / 0 / <0 */

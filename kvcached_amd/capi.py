@@ -87,6 +87,7 @@ SIGNATURES = {
     "kvc_pa_start_prealloc_thread": (_int, [_vp]),
     "kvc_pa_stop_prealloc_thread": (_int, [_vp]),
     "kvc_pa_alloc_page": (_i64, [_vp]),
+    "kvc_pa_alloc_pages": (_i64, [_vp, _i64, _I64P]),
     "kvc_pa_free_page": (_int, [_vp, _i64]),
     "kvc_pa_free_pages": (_int, [_vp, _I64P, _sz]),
     "kvc_pa_resize": (_int, [_vp, _i64]),

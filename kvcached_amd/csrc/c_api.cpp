@@ -270,6 +270,14 @@ int kvc_pa_stop_prealloc_thread(kvc_page_allocator_t *pa) {
 int64_t kvc_pa_alloc_page(kvc_page_allocator_t *pa) {
   return guarded([&]() -> int64_t { return A(pa)->alloc_page(); });
 }
+int64_t kvc_pa_alloc_pages(kvc_page_allocator_t *pa, int64_t n, int64_t *out_ids) {
+  return guarded([&]() -> int64_t {
+    if (n > 0 && !out_ids) throw InvalidError("out_ids is NULL");
+    auto ids = A(pa)->alloc_pages(n);
+    std::copy(ids.begin(), ids.end(), out_ids);
+    return (int64_t)ids.size();
+  });
+}
 int kvc_pa_free_page(kvc_page_allocator_t *pa, int64_t page_id) {
   return guarded([&]() -> int {
     A(pa)->free_page(page_id);

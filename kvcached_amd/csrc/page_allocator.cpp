@@ -131,6 +131,66 @@ page_id_t PageAllocator::alloc_page() { // :161-237
   return pid;
 }
 
+// Addition (no reference counterpart): what n consecutive alloc_page() calls would hand out - reserved pages
+// from the front first, then virtual pages from the front of the free list - but the pages that need backing go
+// through ONE map call (one TLB invalidation, one broadcast to the TP workers) instead of n. All-or-nothing: a
+// failure puts every id back where it was.
+std::vector<page_id_t> PageAllocator::alloc_pages(int64_t n) {
+  std::vector<page_id_t> out, to_map;
+  if (n <= 0) return out;
+  out.reserve(static_cast<size_t>(n));
+  size_t from_reserved = 0;
+  {
+    std::unique_lock<std::mutex> lk(lock_);
+    while (static_cast<int64_t>(out.size()) < n && !reserved_list_.empty()) {
+      out.push_back(reserved_list_.front());
+      reserved_list_.pop_front();
+      num_free_pages_--;
+    }
+    from_reserved = out.size();
+    while (static_cast<int64_t>(out.size() + to_map.size()) < n && !free_list_.empty()) {
+      to_map.push_back(free_list_.front());
+      free_list_.pop_front();
+      num_free_pages_--;
+    }
+    if (from_reserved) {
+      if (reserved_list_.size() < static_cast<size_t>(min_reserved_)) {
+        prealloc_needed_ = true;
+        cond_.notify_all();
+      }
+      publish_usage();
+    }
+  }
+  if (!to_map.empty()) {
+    try {
+      map_pages(to_map.data(), to_map.size());
+    } catch (const std::exception &e) {
+      std::lock_guard<std::mutex> g(lock_);
+      free_list_.insert(free_list_.begin(), to_map.begin(), to_map.end());
+      reserved_list_.insert(reserved_list_.begin(), out.begin(), out.begin() + static_cast<std::ptrdiff_t>(from_reserved));
+      num_free_pages_ += static_cast<int64_t>(to_map.size() + from_reserved);
+      publish_usage();
+      cond_.notify_all();
+      throw std::runtime_error("Failed to map page " + std::to_string(to_map.front()) + ": " + e.what());
+    }
+    out.insert(out.end(), to_map.begin(), to_map.end());
+    std::lock_guard<std::mutex> g(lock_);
+    if (enable_page_prealloc_) {
+      prealloc_needed_ = true;
+      cond_.notify_all();
+    }
+    publish_usage();
+  }
+  // pages the prealloc thread is holding right now (or none left at all): the one-by-one path knows how to wait
+  try {
+    while (static_cast<int64_t>(out.size()) < n) out.push_back(alloc_page());
+  } catch (...) {
+    if (!out.empty()) free_pages(out.data(), out.size());
+    throw;
+  }
+  return out;
+}
+
 void PageAllocator::free_page(page_id_t page_id) { // :239-262
   {
     std::lock_guard<std::mutex> g(lock_);

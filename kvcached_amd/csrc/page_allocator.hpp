@@ -66,6 +66,9 @@ public:
   ~PageAllocator();
 
   page_id_t alloc_page();
+  // n pages with ONE map call for those that need backing (addition; same ids, same offsets in the same order
+  // as n alloc_page() calls, all-or-nothing)
+  std::vector<page_id_t> alloc_pages(int64_t n);
   void free_page(page_id_t page_id);
   void free_pages(const page_id_t *page_ids, size_t n);
   bool resize(int64_t new_mem_size);

@@ -232,6 +232,19 @@ public:
     if (pid < 0) raise_last((int)pid);
     return std::make_shared<PyInternalPage>(pid, page_size_);
   }
+  // addition: n pages, one map call for those that need backing (see kvc_pa_alloc_pages)
+  std::vector<std::shared_ptr<PyInternalPage>> alloc_pages(int64_t n) {
+    std::vector<int64_t> ids((size_t)std::max<int64_t>(n, 1));
+    int64_t k;
+    {
+      py::gil_scoped_release nogil;
+      k = kvc_pa_alloc_pages(pa_, n, ids.data());
+    }
+    if (k < 0) raise_last((int)k);
+    std::vector<std::shared_ptr<PyInternalPage>> out;
+    for (int64_t i = 0; i < k; ++i) out.push_back(std::make_shared<PyInternalPage>(ids[(size_t)i], page_size_));
+    return out;
+  }
   void free_page(int64_t page_id) {
     py::gil_scoped_release nogil;
     check(kvc_pa_free_page(pa_, page_id));
@@ -382,6 +395,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("start_prealloc_thread", &PyPageAllocator::start_prealloc_thread)
       .def("stop_prealloc_thread", &PyPageAllocator::stop_prealloc_thread)
       .def("alloc_page", &PyPageAllocator::alloc_page)
+      .def("alloc_pages", &PyPageAllocator::alloc_pages)
       .def("free_page", &PyPageAllocator::free_page)
       .def("free_pages", &PyPageAllocator::free_pages)
       .def("resize", &PyPageAllocator::resize)

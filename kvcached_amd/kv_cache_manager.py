@@ -29,6 +29,7 @@ from kvcached_amd import vmm_ops as _ops
 from kvcached_amd.locks import NoOpLock
 from kvcached_amd.tp_ipc_util import broadcast_kv_tensors_created
 from kvcached_amd.utils import (
+    BATCH_PAGE_ALLOC,
     CONTIGUOUS_LAYOUT,
     DEFAULT_IPC_NAME,
     PAGE_PREALLOC_ENABLED,
@@ -96,6 +97,8 @@ class KVCacheManager:
         self.reserve_null_block = reserve_null_block
         self.group_id = group_id
         self.page_size = PAGE_SIZE
+        # uniform blocks per page (0 when blocks straddle page edges: then pages differ and nothing is batched)
+        self._blocks_per_page = PAGE_SIZE // self.block_mem_size if PAGE_SIZE % self.block_mem_size == 0 else 0
         if self.block_mem_size > self.page_size:
             # no block would fit a page: the pool would stay empty and the engine would hang in
             # warm-up (hybrid linear-attention states can be this large) — refuse with the fix
@@ -232,12 +235,20 @@ class KVCacheManager:
             from_reserved = take
 
         bms = self.block_mem_size
+        fresh: List[Any] = []  # pages backed ahead for this call, in the order the loop below consumes them
         try:
+            if BATCH_PAGE_ALLOC:
+                # how many new pages the loop below will ask for: what the partially used pages cannot cover
+                bpp = self._blocks_per_page
+                beyond = missing - self.num_avail_blocks
+                if bpp > 0 and beyond > bpp:  # two or more: back them with one map call
+                    fresh = self.page_allocator.alloc_pages(-(-beyond // bpp))
+                    fresh.reverse()  # consumed with pop()
             while missing > 0:
                 if self.avail_pages:
                     _, page = self.avail_pages.popitem()  # most recently touched partial page
                 else:
-                    page = self.page_allocator.alloc_page()
+                    page = fresh.pop() if fresh else self.page_allocator.alloc_page()
                     page.init(bms)
                     if page.num_free_blocks() == 0:
                         # every aligned block of this page straddles its edge: park it where free()
@@ -257,6 +268,8 @@ class KVCacheManager:
             self.reserved_blocks = out[:from_reserved] + self.reserved_blocks
             if taken_from_pages:
                 self.free(taken_from_pages)
+            if fresh:
+                self.page_allocator.free_pages([p.page_id for p in reversed(fresh)])
             raise
         return out
 

@@ -45,6 +45,9 @@ PAGE_SIZE = _get_page_size()
 # ---- allocator knobs (utils.py:127-147); the native core reads the same variables itself
 GPU_UTILIZATION = float(os.getenv("KVCACHED_GPU_UTILIZATION", "0.95"))
 PAGE_PREALLOC_ENABLED = _env_flag("KVCACHED_PAGE_PREALLOC_ENABLED", "true")
+# addition: an alloc() that needs several new pages backs them with ONE map call (same page ids, same offsets in the
+# same order as the reference's page-by-page loop; one TLB invalidation / one TP broadcast instead of one per page)
+BATCH_PAGE_ALLOC = _env_flag("KVCACHED_BATCH_PAGE_ALLOC", "true")
 MIN_RESERVED_PAGES = int(os.getenv("KVCACHED_MIN_RESERVED_PAGES", "5"))
 MAX_RESERVED_PAGES = int(os.getenv("KVCACHED_MAX_RESERVED_PAGES", "10"))
 MAX_CACHED_BLOCKS = int(os.getenv("KVCACHED_MAX_CACHED_BLOCKS", "1000"))

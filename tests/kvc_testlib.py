@@ -103,6 +103,18 @@ def replay(ad: Adapter, ops: List[List[Any]], full: bool = False) -> List[Dict[s
     return out
 
 
+def merge_events(ev: List[List[Any]]) -> List[List[Any]]:
+    """Consecutive map (or unmap) calls folded into one with the offsets concatenated: what is left when only the
+    call boundaries differ (KVCACHED_BATCH_PAGE_ALLOC)."""
+    out: List[List[Any]] = []
+    for kind, offs in ev:
+        if out and out[-1][0] == kind:
+            out[-1][1] = out[-1][1] + list(offs)
+        else:
+            out.append([kind, list(offs)])
+    return out
+
+
 def chain_hash(records: List[Dict[str, Any]], every: int = 100) -> Dict[str, Any]:
     """Running sha256 over the JSON of each record; checkpoints localise a mismatch."""
     import json
@@ -321,12 +333,15 @@ class ProductAdapter(Adapter):
 
     def __init__(self, num_blocks, block_size, cell_size, num_layers, world_size=1, reserve_null_block=False,
                  num_kv_buffers=2, contiguous=False, phys_pages=1 << 40, group_id=0, device="cpu", execute=False,
-                 page_size=PAGE):
+                 page_size=PAGE, batch_page_alloc=False):
         import kvcached_amd.kv_cache_manager as kcm
         from kvcached_amd import vmm_ops
         self.kcm, self.ops = kcm, vmm_ops
         self.geom = (page_size, num_layers, num_kv_buffers)
         kcm.CONTIGUOUS_LAYOUT = contiguous
+        # False = the reference's page-by-page map calls (what the goldens record, call by call); True = the
+        # product default: one map call per alloc(), same offsets in the same order (compare with merge_events)
+        kcm.BATCH_PAGE_ALLOC = batch_page_alloc
         vmm_ops.init_kvcached(device, page_size, contiguous)
         self.real_phys = device != "cpu" and phys_pages >= PHYS_CAP
         if not self.real_phys:

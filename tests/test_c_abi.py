@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_channel():
     from kvcached_amd import capi
-    assert capi.lib.kvc_abi_version() == 3
+    assert capi.lib.kvc_abi_version() == 4
     assert capi.lib.kvc_set_option(999, 1) == capi.KVC_E_INVALID
     assert capi.last_error() == "unknown option"
     assert capi.lib.kvc_get_device(None, None) == capi.KVC_E_INVALID  # not initialised

@@ -305,6 +305,16 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
         assert st["handles_created"] == 5 and st["handles_released"] == 5      # the partial batch was undone
         after = (m.available_size(), m.page_allocator.get_num_free_pages(), m.page_allocator._page_list(0))
         assert after == before
+        # the batched path: 300 blocks need 4 new page ids = 32 slots in ONE map call; the 21st create fails
+        capi.reset_stats()
+        capi.set_option(104, 20)
+        with pytest.raises(RuntimeError, match=r"Failed to map page 1: .*hipMemCreate.*\[injected\]"):
+            m.alloc(300)
+        capi.set_option(104, -1)
+        st = capi.get_stats()
+        assert st["handles_created"] == 20 and st["handles_released"] == 20
+        after = (m.available_size(), m.page_allocator.get_num_free_pages(), m.page_allocator._page_list(0))
+        assert after == before
         # nothing of page 1 is left mapped (lazy mode: it can be mapped again from scratch), and the retry works
         got = m.alloc(100)
         assert got == list(range(10, 110))

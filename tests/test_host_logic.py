@@ -230,6 +230,12 @@ def test_alloc_is_exception_safe_when_backing_a_page_fails(cpu_ops):
     after = (m.available_size(), list(m.reserved_blocks), m.page_allocator.get_num_free_pages(),
              m.page_allocator._page_list(0), m.num_avail_blocks)
     assert after == before
+    # the batched path (several new pages, ONE map call): all-or-nothing as well
+    with pytest.raises(RuntimeError, match="Failed to map page 1"):
+        m.alloc(300)
+    after = (m.available_size(), list(m.reserved_blocks), m.page_allocator.get_num_free_pages(),
+             m.page_allocator._page_list(0), m.num_avail_blocks)
+    assert after == before
     pa.set_broadcast_map_callback(None)
     pa.set_should_use_worker_ipc_callback(None)
     got = m.alloc(100)

@@ -159,3 +159,45 @@ def test_manager_large_traces(idx):
         assert got[-5:] == case["records_tail"]
     finally:
         ad.close()
+
+
+# ------------------------------------------------------------------ KVCACHED_BATCH_PAGE_ALLOC (the product default)
+def _merged(records):
+    return [{"r": r["r"], "s": r["s"], "e": T.merge_events(r["e"])} for r in records]
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_small_traces_with_batched_page_alloc(idx):
+    """An alloc() that needs several new pages backs them with ONE map call. Against the reference's recorded traces
+    everything is identical - results, every counter, the shm triple, the offsets and their order - except the call
+    boundaries: the golden's consecutive map calls of one alloc() arrive folded into one."""
+    case = load("manager_small.json")["cases"][idx]
+    ad = _adapter(case["config"], batch_page_alloc=True)
+    try:
+        init = {"s": ad.snapshot(), "e": ad.drain_events()}
+        assert init == case["init"], case["name"]
+        got = T.replay(ad, case["ops"], full=True)
+        for i, (g, want) in enumerate(zip(_merged(got), _merged(case["records"]))):
+            assert g == want, f"{case['name']} op {i} {case['ops'][i]}"
+    finally:
+        ad.close()
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_large_traces_with_batched_page_alloc(idx):
+    """The large goldens only hold hashes, so the batched run is compared with the page-by-page run of the product
+    (which test_manager_large_traces pins to the reference): equal after folding consecutive map calls."""
+    case = load("manager_large.json")["cases"][idx]
+    runs = []
+    for batch in (False, True):
+        ad = _adapter(case["config"], batch_page_alloc=batch)
+        try:
+            ad.drain_events()
+            runs.append(T.replay(ad, case["ops"], full=True))
+        finally:
+            ad.close()
+    assert _merged(runs[0]) == _merged(runs[1])
+    calls = [sum(len(r["e"]) for r in run) for run in runs]
+    assert calls[1] <= calls[0]
+    if any(len([e for e in r["e"] if e[0] == 0]) > 1 for r in runs[0]):
+        assert calls[1] < calls[0]                               # some alloc needed several pages: fewer calls now
