@@ -5,7 +5,25 @@ With a synchronous scheduler only one thread ever touches the KVCacheManager, so
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+from typing import Any, Callable, Optional, Protocol
+
+
+class LockLike(Protocol):
+    """Structural type of what `@synchronized` needs: threading.RLock and NoOpLock both fit (reference :7-19)."""
+
+    def acquire(self, blocking: bool = True, timeout: float = -1) -> bool: ...
+    def release(self) -> None: ...
+    def __enter__(self) -> bool: ...
+    def __exit__(self, exc_type: Any, exc_val: Any, exc_tb: Any) -> None: ...
+
+
+class ConditionLike(Protocol):
+    """Structural type shared by threading.Condition and NoOpCondition (reference :22-48)."""
+
+    def wait(self, timeout: Optional[float] = None) -> bool: ...
+    def wait_for(self, predicate: Callable[[], bool], timeout: Optional[float] = None) -> bool: ...
+    def notify(self, n: int = 1) -> None: ...
+    def notify_all(self) -> None: ...
 
 
 class NoOpLock:
