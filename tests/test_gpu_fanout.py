@@ -44,8 +44,15 @@ print("FANOUT_OK")
 """
 
 
+def _free_port() -> str:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _env():
-    env = dict(os.environ, KVC_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1",
+    env = dict(os.environ, KVC_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", KVCACHED_LOG_LEVEL="ERROR", HSA_ENABLE_IPC_MODE_LEGACY="0")
     return env
 
@@ -58,7 +65,7 @@ def test_collective_fanout_over_rccl_single_rank():
 def test_bench_distributed_path_single_rank():
     """bench.py with the process group forced on: the line must come out with the N>1 fan-out in `config`."""
     env = _env()
-    env.update(KVC_BENCH_FORCE_DIST="1", MASTER_PORT="29672")
+    env.update(KVC_BENCH_FORCE_DIST="1")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                           "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

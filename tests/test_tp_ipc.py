@@ -157,7 +157,10 @@ def _collective_worker(rank, world, port, q):
 def test_collective_fanout_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    import socket
+    with socket.socket() as sk:          # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_collective_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
