@@ -342,8 +342,28 @@ def reference_on_box(steps, warmup, burst=False):
         return {"error": str(e)[:200]}
 
 
+def ensure_built(local_rank: int) -> None:
+    """The in-tree .so files normally travel with the repo; if they are missing, local rank 0 compiles them (hipcc,
+    gfx950) while the other ranks wait. This only builds the product - there is no fallback to fall back to."""
+    import glob
+    pkg = os.path.join(REPO, "kvcached_amd")
+    have = lambda: os.path.exists(os.path.join(pkg, "libkvcached_amd.so")) and glob.glob(os.path.join(pkg, "vmm_ops.*.so"))  # noqa: E731
+    if have():
+        return
+    if local_rank == 0:
+        subprocess.check_call([sys.executable, "-m", "kvcached_amd.build"], cwd=REPO, stdout=sys.stderr)
+        return
+    t0 = time.time()
+    while not have():
+        if time.time() - t0 > 600:
+            raise SystemExit("bench.py: the native extension was not built by local rank 0 within 10 minutes")
+        time.sleep(1.0)
+    time.sleep(2.0)  # let the linker finish writing
+
+
 def main():
     args = parse_args()
+    ensure_built(int(os.environ.get("LOCAL_RANK", "0")))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
