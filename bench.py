@@ -351,7 +351,7 @@ def ensure_built(local_rank: int) -> None:
     if have():
         return
     if local_rank == 0:
-        subprocess.check_call([sys.executable, "-m", "kvcached_amd.build"], cwd=REPO, stdout=sys.stderr)
+        subprocess.check_call([sys.executable, os.path.join(REPO, "kvcached_amd", "build.py")], cwd=REPO, stdout=sys.stderr)
         return
     t0 = time.time()
     while not have():

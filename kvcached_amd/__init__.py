@@ -19,7 +19,7 @@ def _require_native():
     except ImportError as e:  # fail loudly, never degrade
         raise ImportError(
             "kvcached_amd: the native extension (libkvcached_amd.so + vmm_ops) is missing or does not load: "
-            f"{e}. Build it in-tree with `python -m kvcached_amd.build` (needs hipcc, --offload-arch=gfx950).") from e
+            f"{e}. Build it in-tree with `python kvcached_amd/build.py` (needs hipcc, --offload-arch=gfx950).") from e
 
 
 _require_native()

@@ -6,7 +6,7 @@ sources so that they travel to the GPU box with the repo snapshot).
   vmm_ops.<abi>.so     pybind11/torch module with the reference's `kvcached.vmm_ops` surface,
                        a thin layer over the C ABI; built with g++ against the installed torch
 
-Usage: python -m kvcached_amd.build [--force]
+Usage: python kvcached_amd/build.py [--force]
 """
 from __future__ import annotations
 

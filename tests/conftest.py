@@ -25,7 +25,10 @@ def pytest_configure(config):
     # checkers and product are built once per session; both are no-ops when up to date
     if not os.path.exists(os.path.join(REPO, "oracle", "libkvc_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "oracle"])
-    from kvcached_amd import build as kb
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kvcached_amd_build", os.path.join(REPO, "kvcached_amd", "build.py"))
+    kb = importlib.util.module_from_spec(spec)   # by path: the package itself refuses to import without the extension
+    spec.loader.exec_module(kb)
     try:
         stale = kb._stale(kb.LIB, kb.LIB_DEPS) or kb._stale(kb.EXT, kb.EXT_SRCS)
     except OSError:
