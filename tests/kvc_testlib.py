@@ -338,6 +338,7 @@ class ProductAdapter(Adapter):
         from kvcached_amd import vmm_ops
         self.kcm, self.ops = kcm, vmm_ops
         self.geom = (page_size, num_layers, num_kv_buffers)
+        self._saved_globals = (kcm.CONTIGUOUS_LAYOUT, kcm.BATCH_PAGE_ALLOC)   # restored by close()
         kcm.CONTIGUOUS_LAYOUT = contiguous
         # False = the reference's page-by-page map calls (what the goldens record, call by call); True = the
         # product default: one map call per alloc(), same offsets in the same order (compare with merge_events)
@@ -401,6 +402,7 @@ class ProductAdapter(Adapter):
         from kvcached_amd import capi
         self.m = None
         self.tensors = None
+        self.kcm.CONTIGUOUS_LAYOUT, self.kcm.BATCH_PAGE_ALLOC = self._saved_globals
         self.ops.shutdown_kvcached()
         capi.set_mem_info_override(0, 0)
 

@@ -288,6 +288,7 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    monkeypatch.setattr(kcm, "BATCH_PAGE_ALLOC", True)
     vmm_ops.init_kvcached(DEV, T.PAGE, False)
     capi.set_option(capi.OPT_POOL_BYTES, 0)             # every handle must be created
     try:

@@ -212,6 +212,7 @@ def test_alloc_is_exception_safe_when_backing_a_page_fails(cpu_ops):
     The GPU twin with an injected hipMemCreate failure is tests/test_gpu_manager.py."""
     ops, capi = cpu_ops
     import kvcached_amd.kv_cache_manager as kcm
+    kcm.BATCH_PAGE_ALLOC = True                                # the product default (tests before may have left it off)
     ops.create_kv_tensors(16 * PAGE * 2, 1, "cpu", 2, 2, 0, False)
     m = kcm.KVCacheManager(num_blocks=16 * 64, block_size=16, cell_size=2048, num_layers=2)
     assert m._post_init_done.wait(10)
