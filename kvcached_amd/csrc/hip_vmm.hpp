@@ -144,6 +144,10 @@ public:
 
   // Takes handles back. What exceeds the cap (or everything, under memory pressure) goes to the
   // driver in creation order, oldest first.
+  // With a housekeeping thread around (defer_eviction), what exceeds the cap is NOT released here, on the
+  // caller's free() path - hipMemRelease of a used handle costs 40-50 us, 200 ms for a 4096-slot free - but
+  // by trim_to_cap() from that thread, a tick later. Under memory pressure the release is immediate either way.
+  void set_defer_eviction(bool on) { defer_eviction_.store(on); }
   void release_batch(Phys *ps, size_t n) {
     if (n == 0) return;
     std::vector<Phys> victims;
@@ -151,7 +155,7 @@ public:
     {
       std::lock_guard<std::mutex> g(mu_);
       for (size_t i = 0; i < n; ++i) idle_.emplace(ps[i].seq, ps[i].h);
-      const size_t keep = pressure ? 0 : cap_handles_;
+      const size_t keep = pressure ? 0 : (defer_eviction_.load() && cap_handles_ > 0 ? (size_t)-1 : cap_handles_);
       while (idle_.size() > keep) {
         auto it = idle_.begin();
         victims.push_back(Phys{it->second, it->first});
@@ -159,6 +163,22 @@ public:
       }
     }
     to_driver(victims);
+  }
+
+  // Housekeeping: bring the idle set back under its cap, at most `max_release` handles per call, oldest first.
+  size_t trim_to_cap(size_t max_release) {
+    std::vector<Phys> victims;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      while (idle_.size() > cap_handles_ && victims.size() < max_release) {
+        auto it = idle_.begin();
+        victims.push_back(Phys{it->second, it->first});
+        idle_.erase(it);
+      }
+      low_water_ = std::min(low_water_, idle_.size());
+    }
+    to_driver(victims);
+    return victims.size();
   }
 
   // Give idle memory back to the driver, keeping at most `keep` (the youngest) handles.
@@ -246,6 +266,7 @@ private:
   VmmCounters *ctr_;
   size_t cap_handles_ = 0;
   std::function<void()> before_driver_release_;
+  std::atomic<bool> defer_eviction_{false};
   std::atomic<uint64_t> next_seq_{0};
   std::mutex mu_;
   std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle

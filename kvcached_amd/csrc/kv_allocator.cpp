@@ -104,6 +104,7 @@ PhysPool *GpuContext::pool(size_t granule, bool exportable) {
   if (it == m.end()) {
     it = m.emplace(granule, std::make_unique<PhysPool>(dev_, granule, exportable, &stats().vmm)).first;
     it->second->set_before_driver_release([this]() { flush_deferred_shootdown(); });
+    it->second->set_defer_eviction(housekeepers_.load() > 0);
   }
   it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   return it->second.get();
@@ -127,6 +128,20 @@ size_t GpuContext::idle_pool_bytes() {
   return b;
 }
 
+void GpuContext::add_housekeeper(int delta) {
+  const bool on = housekeepers_.fetch_add(delta) + delta > 0;
+  std::vector<PhysPool *> ps;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto &m : pools_)
+      for (auto &kv : m) ps.push_back(kv.second.get());
+  }
+  for (auto *p : ps) {
+    p->set_defer_eviction(on);
+    if (!on) p->trim_to_cap((size_t)-1); // nobody will do it later
+  }
+}
+
 void GpuContext::housekeeping() {
   std::vector<PhysPool *> ps;
   {
@@ -140,6 +155,7 @@ void GpuContext::housekeeping() {
     for (auto *p : ps) p->drain(0);
     return;
   }
+  for (auto *p : ps) p->trim_to_cap(1024); // what release_batch left above the cap (deferred eviction)
   const int64_t idle_ms = options().pool_idle_ms.load();
   if (idle_ms > 0)
     for (auto *p : ps) p->decay(now_ns(), idle_ms * 1000000ll, 1024);

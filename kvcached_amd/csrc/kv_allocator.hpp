@@ -71,6 +71,9 @@ public:
   // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
   // let handles that sat idle for KVCACHED_POOL_IDLE_MS go back to the driver (PhysPool::decay)
   void housekeeping();
+  // a thread that calls housekeeping() periodically exists / is gone (PageAllocator's watcher): while one does,
+  // pools hand over-cap handles to it instead of releasing them on the caller's free() path
+  void add_housekeeper(int delta);
 
   // kernel launches on `s` (NULL = own stream), timed with events when profiling is on
   void zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s);
@@ -107,6 +110,7 @@ private:
   int dev_;
   hipStream_t stream_ = nullptr;
   std::atomic<bool> tlb_owed_{false};
+  std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];
   std::vector<Timed> inflight_;

@@ -437,6 +437,7 @@ void PageAllocator::start_prealloc_thread() { // :524-528, :717-733
   if (!watcher_thread_) {
     watcher_running_ = true;
     watcher_thread_ = std::make_unique<std::thread>(&PageAllocator::resize_watcher, this);
+    if (GpuContext *ctx = KvAllocator::gpu()) ctx->add_housekeeper(+1); // it also runs the handle pools' housekeeping
   }
 }
 
@@ -460,7 +461,10 @@ void PageAllocator::stop_threads() { // :735-755
     watcher_cv_.notify_all();
     w = std::move(watcher_thread_);
   }
-  if (w && w->joinable()) w->join();
+  if (w && w->joinable()) {
+    w->join();
+    if (GpuContext *ctx = KvAllocator::gpu()) ctx->add_housekeeper(-1);
+  }
 }
 
 void PageAllocator::prealloc_worker() { // :536-617

@@ -382,3 +382,41 @@ def test_golden_trace_with_async_unmap(monkeypatch):
     finally:
         ad.close()
         capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
+
+
+def test_pool_eviction_is_left_to_the_housekeeping_thread(monkeypatch):
+    """With an allocator watcher thread around, handles that exceed the pool's cap are not released on the caller's
+    free() path (hipMemRelease of a used handle is 40-50 us: 200 ms for a 4096-slot free) but by the 10 Hz
+    housekeeping; without one (plain C-ABI use) the release stays immediate."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)          # starts the prealloc + watcher threads
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    capi.set_option(capi.OPT_POOL_BYTES, 16 * T.PAGE)                  # a 16-handle pool
+    try:
+        vmm_ops.create_kv_tensors(64 * T.PAGE * 2, 1, DEV, 2, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=64 * 64, block_size=16, cell_size=2048, num_layers=2)
+        assert m._post_init_done.wait(10)
+        ids = m.alloc(40 * 64)                                         # 40 page ids = 160 slots
+        time.sleep(0.3)
+        capi.reset_stats()
+        m.free(ids)                                                    # 10 page ids stay reserved, 120 slots unmapped
+        st = capi.get_stats()
+        assert st["pages_unmapped"] >= 100 and st["handles_released"] == 0, st
+        t0 = time.time()
+        while capi.get_stats()["handles_released"] < st["pages_unmapped"] - 16 and time.time() - t0 < 5:
+            time.sleep(0.05)
+        assert capi.get_stats()["handles_released"] >= st["pages_unmapped"] - 16
+        del m
+        # no watcher any more: the same free releases at once
+        vmm_ops.create_kv_tensors(64 * T.PAGE * 2, 1, DEV, 2, 2, 0, False)
+        offs = [i * T.PAGE for i in range(30)]
+        assert vmm_ops.map_to_kv_tensors(offs)
+        capi.reset_stats()
+        assert vmm_ops.unmap_from_kv_tensors(offs)
+        st = capi.get_stats()
+        assert st["handles_released"] >= st["pages_unmapped"] - 16
+    finally:
+        capi.set_option(capi.OPT_POOL_BYTES, 16384 << 20)
+        vmm_ops.shutdown_kvcached()
