@@ -73,8 +73,9 @@ class Pool:
     """One region of `window` batches, driven through the C ABI."""
 
     def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
-                 compound_layers: int = 0):
+                 compound_layers: int = 0, backend: str = "hip"):
         self.capi, self.device, self.window = capi, device, window_batches
+        os.environ["KVCACHED_VMM_BACKEND"] = backend
         os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
         if pool_mb is not None:
             os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
@@ -96,6 +97,7 @@ class Pool:
 
     def close(self):
         self.capi.shutdown()
+        os.environ["KVCACHED_VMM_BACKEND"] = "hip"
 
 
 def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
@@ -110,14 +112,14 @@ def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
 
 
 def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0,
-            burst=False, prefault=True):
+            burst=False, prefault=True, backend="hip"):
     """cycle (default): every step maps+zeroes one batch and unmaps it again. burst=True: `steps` batches are
     backed one after the other and only unmapped after the timed region.
     prefault: as in the bench_vmm protocol (warm-up sweeps over the whole window before the timed sweeps), every batch
     of the window is mapped and unmapped once during set-up - the state of an engine that has been running for a
     second. prefault=False skips the sweep (the timed steps then touch VA that was never mapped)."""
     window = max(32, steps + warmup) if burst else 32  # 64 GiB of VA
-    pool = Pool(capi, device, window, mode, pool_mb, compound_layers=compound_layers)
+    pool = Pool(capi, device, window, mode, pool_mb, compound_layers=compound_layers, backend=backend)
     slot = pool.slot
     try:
         if fanout is not None:
@@ -439,14 +441,19 @@ def main():
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
+                        ("hsa_vmm_backend_opt_in", "lazy", None, 0, False, True),
+                        ("hsa_growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),
+                        ("hsa_no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
+                        ("hsa_compat_zero_backfill_sharded", "compat", None, 0, False, True),
                         ("fresh_va_window_warm_process", "lazy", None, 0, False, False),
                         ("growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),   # growth = fresh VA, fresh handles
                         ("no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
                         ("compat_zero_backfill_sharded", "compat", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
-                        nsteps = 24 if (burst or name.startswith("fresh_va")) else 8
-                        r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre)
+                        nsteps = 24 if (burst or name.startswith("fresh_va") or name == "hsa_vmm_backend_opt_in") else 8
+                        r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
+                                     backend="hsa" if name.startswith("hsa_") else "hip")
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
                                           for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",

@@ -12,6 +12,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -20,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -45,7 +48,102 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 }
 #define HIP_CHECK(expr) ::kvc::hip_check((expr), #expr, __FILE__, __LINE__)
 
-using phys_handle_t = hipMemGenericAllocationHandle_t;
+// ---------------------------------------------------------------------------------------------------------
+// Two ways to the same driver. The physical-memory API of HIP sits on ROCr's hsa_amd_vmem_*; on ROCm 7.x
+// hipMemUnmap additionally pushes a marker through the GPU queue and spins on its signal - ~10 of its 12-15 us
+// (tools/unmap_trace.cpp: 2.7 us of ioctls, the rest user-time spinning inside hsa_signal_wait). Talking to ROCr
+// directly, map + set_access + unmap cost 2.3 + 3.0 + 2.8 us per 2 MiB mapping instead of 3.1 + 3.3 + 14.5
+// (tools/hsa_vmm_probe.cpp, same box). The price: HIP never learns about such mappings. Kernels (raw pointers),
+// device-to-device hipMemcpy, hipMemset and hipPointerGetAttributes work on them; a host<->device hipMemcpy takes
+// the pointer for pageable host memory and crashes. Hence: HIP is the default backend (every torch operation
+// works on the KV tensors), KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only.
+using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer) or hsa_amd_vmem_alloc_handle_t::handle
+
+enum : int { kVmmHip = 0, kVmmHsa = 1 };
+inline std::atomic<int> &vmm_backend() { // set by KvAllocator::init from KVCACHED_VMM_BACKEND; fixed while handles exist
+  static std::atomic<int> v{kVmmHip};
+  return v;
+}
+
+inline void hsa_check(hsa_status_t st, const char *tok, const char *file, int line) {
+  if (st == HSA_STATUS_SUCCESS) return;
+  const char *msg = "unknown";
+  (void)hsa_status_string(st, &msg);
+  char buf[512];
+  const char *base = strrchr(file, '/');
+  snprintf(buf, sizeof buf, "%s:%d %s failed in ROCr (0x%x): %s", base ? base + 1 : file, line, tok, (unsigned)st, msg);
+  if (env_bool("KVCACHED_STRICT_ABORT", false)) {
+    fprintf(stderr, "%s\n", buf);
+    std::abort();
+  }
+  throw GpuError(buf);
+}
+#define HSA_CHECK(expr) ::kvc::hsa_check((expr), #expr, __FILE__, __LINE__)
+
+// The ROCr agent and its coarse-grained local pool behind a HIP device index (matched by PCI address).
+struct HsaDevice {
+  hsa_agent_t agent{};
+  hsa_amd_memory_pool_t pool{};
+};
+inline const HsaDevice &hsa_device(int hip_dev) {
+  static std::mutex mu;
+  static std::unordered_map<int, HsaDevice> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(hip_dev);
+  if (it != cache.end()) return it->second;
+  HSA_CHECK(hsa_init()); // HIP has initialised ROCr already: this only takes a reference
+  int bus = -1, dev = -1, dom = 0;
+  HIP_CHECK(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_dev));
+  HIP_CHECK(hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_dev));
+  (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_dev);
+  (void)hipGetLastError();
+  struct Find {
+    int bus, dev, dom;
+    bool found = false;
+    HsaDevice d;
+  } f{bus, dev, dom};
+  HSA_CHECK(hsa_iterate_agents(
+      [](hsa_agent_t a, void *p) -> hsa_status_t {
+        auto *f = static_cast<Find *>(p);
+        hsa_device_type_t t;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU)
+          return HSA_STATUS_SUCCESS;
+        uint32_t bdf = 0, domain = 0;
+        (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+        (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+        if ((int)((bdf >> 8) & 0xff) == f->bus && (int)((bdf >> 3) & 0x1f) == f->dev && (int)domain == f->dom && !f->found) {
+          f->d.agent = a;
+          f->found = true;
+        }
+        return HSA_STATUS_SUCCESS;
+      },
+      &f));
+  if (!f.found) throw GpuError("no ROCr agent matches HIP device " + std::to_string(hip_dev));
+  struct Pool {
+    bool found = false;
+    hsa_amd_memory_pool_t p{};
+  } pool;
+  HSA_CHECK(hsa_amd_agent_iterate_memory_pools(
+      f.d.agent,
+      [](hsa_amd_memory_pool_t p, void *q) -> hsa_status_t {
+        auto *out = static_cast<Pool *>(q);
+        hsa_amd_segment_t seg;
+        uint32_t flags = 0;
+        bool alloc = false;
+        (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+        (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+        (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+        if (seg == HSA_AMD_SEGMENT_GLOBAL && alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !out->found) {
+          out->p = p;
+          out->found = true;
+        }
+        return HSA_STATUS_SUCCESS;
+      },
+      &pool));
+  if (!pool.found) throw GpuError("ROCr agent of HIP device " + std::to_string(hip_dev) + " has no coarse-grained local pool");
+  f.d.pool = pool.p;
+  return cache.emplace(hip_dev, f.d).first->second;
+}
 
 inline hipMemAllocationProp make_alloc_prop(int dev, bool exportable) {
   hipMemAllocationProp prop{};
@@ -61,6 +159,80 @@ inline hipMemAccessDesc make_rw_access(int dev) {
   d.location.id = dev;
   d.flags = hipMemAccessFlagsProtReadWrite;
   return d;
+}
+inline hipMemGenericAllocationHandle_t as_hip(phys_handle_t h) { return reinterpret_cast<hipMemGenericAllocationHandle_t>(h); }
+inline hsa_amd_vmem_alloc_handle_t as_hsa(phys_handle_t h) { return hsa_amd_vmem_alloc_handle_t{h}; }
+
+// ---- the VMM verbs, in a throwing form (vmm_*) and a quiet one for cleanup / rollback paths (vmm_try_*)
+inline void *vmm_reserve(size_t size, size_t align, void *hint) {
+  void *p = nullptr;
+  if (vmm_backend() == kVmmHsa)
+    HSA_CHECK(hsa_amd_vmem_address_reserve_align(&p, size, reinterpret_cast<uint64_t>(hint), align, 0));
+  else
+    HIP_CHECK(hipMemAddressReserve(&p, size, align, hint, 0));
+  return p;
+}
+inline bool vmm_try_address_free(void *va, size_t size) {
+  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_address_free(va, size) == HSA_STATUS_SUCCESS;
+  return hipMemAddressFree(va, size) == hipSuccess;
+}
+inline phys_handle_t vmm_create(int dev, size_t size, bool exportable) {
+  if (vmm_backend() == kVmmHsa) {
+    hsa_amd_vmem_alloc_handle_t h{};
+    HSA_CHECK(hsa_amd_vmem_handle_create(hsa_device(dev).pool, size, MEMORY_TYPE_PINNED, 0, &h));
+    return h.handle;
+  }
+  hipMemGenericAllocationHandle_t h{};
+  auto prop = make_alloc_prop(dev, exportable);
+  HIP_CHECK(hipMemCreate(&h, size, &prop, 0));
+  return reinterpret_cast<phys_handle_t>(h);
+}
+inline bool vmm_try_release(phys_handle_t h) {
+  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
+  return hipMemRelease(as_hip(h)) == hipSuccess;
+}
+inline void vmm_map(void *va, size_t size, phys_handle_t h) {
+  if (vmm_backend() == kVmmHsa)
+    HSA_CHECK(hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0));
+  else
+    HIP_CHECK(hipMemMap(va, size, 0, as_hip(h), 0));
+}
+inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
+  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
+  return hipMemMap(va, size, 0, as_hip(h), 0) == hipSuccess;
+}
+inline void vmm_set_access(void *va, size_t size, int dev) {
+  if (vmm_backend() == kVmmHsa) {
+    hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hsa_device(dev).agent};
+    HSA_CHECK(hsa_amd_vmem_set_access(va, size, &d, 1));
+  } else {
+    const auto acc = make_rw_access(dev);
+    HIP_CHECK(hipMemSetAccess(va, size, &acc, 1));
+  }
+}
+inline bool vmm_try_set_access(void *va, size_t size, int dev) {
+  if (vmm_backend() == kVmmHsa) {
+    try {
+      hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hsa_device(dev).agent};
+      return hsa_amd_vmem_set_access(va, size, &d, 1) == HSA_STATUS_SUCCESS;
+    } catch (...) {
+      return false;
+    }
+  }
+  const auto acc = make_rw_access(dev);
+  return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
+}
+inline void vmm_unmap(void *va, size_t size) {
+  if (vmm_backend() == kVmmHsa)
+    HSA_CHECK(hsa_amd_vmem_unmap(va, size));
+  else
+    HIP_CHECK(hipMemUnmap(va, size));
+}
+inline bool vmm_try_unmap(void *va, size_t size) {
+  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
+  const bool ok = hipMemUnmap(va, size) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  return ok;
 }
 
 // Test hook: when >= 0, the (n+1)-th hipMemCreate from now fails with hipErrorOutOfMemory (option 104).
@@ -130,10 +302,9 @@ public:
       }
     }
     Phys p;
-    auto prop = make_alloc_prop(dev_, exportable_);
     if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
       hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-    HIP_CHECK(hipMemCreate(&p.h, granule_, &prop, 0));
+    p.h = vmm_create(dev_, granule_, exportable_);
     p.seq = next_seq_.fetch_add(1) + 1;
     ctr_->created++;
     *recycled = false;
@@ -252,8 +423,7 @@ public:
     if (before_driver_release_) before_driver_release_();
     std::sort(v.begin(), v.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; });
     for (auto &p : v) {
-      hipError_t st = hipMemRelease(p.h);
-      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease failed: %s", hipGetErrorString(st));
+      if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
       ctr_->released++;
     }
     (void)hipGetLastError();
@@ -273,11 +443,5 @@ private:
   size_t low_water_ = 0;                         // smallest idle_ size since window_start_ns_
   int64_t window_start_ns_ = 0;
 };
-
-inline void *vmm_reserve(size_t size, size_t align, void *hint) {
-  void *p = nullptr;
-  HIP_CHECK(hipMemAddressReserve(&p, size, align, hint, 0));
-  return p;
-}
 
 } // namespace kvc

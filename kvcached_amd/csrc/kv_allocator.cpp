@@ -389,6 +389,15 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().defer_unmap_shootdown = env_bool("KVCACHED_DEFER_UNMAP_SHOOTDOWN", false) ? 1 : 0;
   options().pool_idle_ms = std::max<int64_t>(0, env_i64("KVCACHED_POOL_IDLE_MS", 1000));
   options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
+  {
+    const char *be = std::getenv("KVCACHED_VMM_BACKEND");
+    const std::string b = be ? be : "hip";
+    if (b != "hip" && b != "hsa") throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip' or 'hsa'");
+    const int want = b == "hsa" ? kVmmHsa : kVmmHip;
+    if (want != vmm_backend().load())
+      for (auto &kv : g_contexts) kv.second->drain_pools(); // pooled handles belong to the backend that made them
+    vmm_backend() = want;
+  }
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));
@@ -607,24 +616,22 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
 // the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
 void KvAllocator::backfill_all(KvRegion &r) {
-  auto acc = make_rw_access(ctx_->dev());
-  auto prop = make_alloc_prop(ctx_->dev(), false);
   r.fanout = (size_t)std::max<int64_t>(1, options().zero_alias_fanout.load());
   const size_t n_zero = (r.num_slots() + r.fanout - 1) / r.fanout;
   r.zero.assign(n_zero, phys_handle_t{});
   size_t made = 0;
   try {
-    for (; made < n_zero; ++made) HIP_CHECK(hipMemCreate(&r.zero[made], r.page_size, &prop, 0));
+    for (; made < n_zero; ++made) r.zero[made] = vmm_create(ctx_->dev(), r.page_size, false);
     const size_t run = (size_t)std::max<int64_t>(1, options().access_run_slots.load());
     for (size_t i = 0; i < r.num_slots(); ++i)
-      HIP_CHECK(hipMemMap(r.base + i * r.page_size, r.page_size, 0, r.zero_of(i), 0));
+      vmm_map(r.base + i * r.page_size, r.page_size, r.zero_of(i));
     for (size_t i = 0; i < r.num_slots(); i += run) {
       size_t k = std::min(run, r.num_slots() - i);
-      HIP_CHECK(hipMemSetAccess(r.base + i * r.page_size, k * r.page_size, &acc, 1));
+      vmm_set_access(r.base + i * r.page_size, k * r.page_size, ctx_->dev());
     }
   } catch (...) {
-    (void)hipMemUnmap(r.base, r.size);
-    for (size_t j = 0; j < made; ++j) (void)hipMemRelease(r.zero[j]);
+    (void)vmm_try_unmap(r.base, r.size);
+    for (size_t j = 0; j < made; ++j) (void)vmm_try_release(r.zero[j]);
     r.zero.clear();
     (void)hipGetLastError();
     throw;
@@ -651,16 +658,14 @@ void KvAllocator::destroy_region(KvRegion &r) {
   // Tolerate stale mappings during teardown: log, do not throw (ftensor.cpp:78-98).
   bool whole = false;
   if (r.backfilled) {
-    hipError_t st = hipMemUnmap(r.base, r.size);
-    whole = st == hipSuccess;
-    if (!whole) KVC_LOG(LOG_ERROR, "hipMemUnmap of whole region %s failed: %s", r.name.c_str(), hipGetErrorString(st));
+    whole = vmm_try_unmap(r.base, r.size);
+    if (!whole) KVC_LOG(LOG_ERROR, "unmapping the whole region %s in one call failed", r.name.c_str());
   }
   std::vector<Phys> dead;
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.mapped[i]) continue;
     if (!whole) {
-      hipError_t st = hipMemUnmap(r.base + i * r.page_size, r.page_size);
-      if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemUnmap during cleanup failed: %s", hipGetErrorString(st));
+      if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size)) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
     dead.push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
@@ -674,16 +679,14 @@ void KvAllocator::destroy_region(KvRegion &r) {
     }
   }
   for (auto &p : dead) {
-    hipError_t st = hipMemRelease(p.h);
-    if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease during cleanup failed: %s", hipGetErrorString(st));
+    if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle during cleanup failed");
     stats().vmm.released++;
   }
   if (r.backfilled && !whole) // aliases that could not be dropped in one call
-    for (size_t i = 0; i < r.num_slots(); ++i) (void)hipMemUnmap(r.base + i * r.page_size, r.page_size);
-  for (auto z : r.zero) (void)hipMemRelease(z);
+    for (size_t i = 0; i < r.num_slots(); ++i) (void)vmm_try_unmap(r.base + i * r.page_size, r.page_size);
+  for (auto z : r.zero) (void)vmm_try_release(z);
   r.zero.clear();
-  hipError_t st = hipMemAddressFree(r.base, r.size);
-  if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemAddressFree during cleanup failed: %s", hipGetErrorString(st));
+  if (!vmm_try_address_free(r.base, r.size)) KVC_LOG(LOG_ERROR, "freeing the VA range of %s failed", r.name.c_str());
   (void)hipGetLastError();
   r.base = nullptr;
 }
@@ -853,7 +856,7 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     KvRegion &r = *s.region;
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
-    HIP_CHECK(hipMemUnmap(r.base + s.index * ps, ps));
+    vmm_unmap(r.base + s.index * ps, ps);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
     *out = Phys{r.handle[s.index], r.seq[s.index]};
@@ -891,7 +894,6 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   PhysPool *pool = ctx->pool(ps, exportable_);
-  const auto acc = make_rw_access(ctx->dev());
   const bool fill = options().zero_fill.load() && !imported;
   const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
 
@@ -925,7 +927,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   auto flush_run = [&]() {
     if (!run_len) return;
     const int64_t ta = now_ns();
-    HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    vmm_set_access(run_start, run_len, ctx->dev());
     stats().t_access += now_ns() - ta;
     dirty_tlb = true;
     if (fill) {
@@ -955,7 +957,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
-      if (r.backfilled) HIP_CHECK(hipMemUnmap(va, ps));
+      if (r.backfilled) vmm_unmap(va, ps);
       int64_t t1 = now_ns();
       bool recycled = false;
       Phys ph;
@@ -971,16 +973,17 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       phys_handle_t h = ph.h;
       int64_t t2 = now_ns();
-      hipError_t st = hipMemMap(va, ps, 0, h, 0);
+      try {
+        vmm_map(va, ps, h);
+      } catch (...) {
+        if (!imported) pool->release(ph);
+        if (r.backfilled && vmm_try_map(va, ps, r.zero_of(s.index))) (void)vmm_try_set_access(va, ps, ctx->dev());
+        throw;
+      }
       int64_t t3 = now_ns();
       stats().t_unmap_alias += t1 - t0;
       stats().t_acquire += t2 - t1;
       stats().t_map += t3 - t2;
-      if (st != hipSuccess) {
-        if (!imported) pool->release(ph);
-        if (r.backfilled && hipMemMap(va, ps, 0, r.zero_of(s.index), 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
-        HIP_CHECK(st);
-      }
       r.handle[s.index] = h;
       r.seq[s.index] = ph.seq;
       r.mapped[s.index] = imported ? 2 : 1;
@@ -1008,13 +1011,13 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     for (auto it = done.rbegin(); it != done.rend(); ++it) {
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
-      (void)hipMemUnmap(va, ps);
+      (void)vmm_try_unmap(va, ps);
       if (r.mapped[it->index] == 1)
         pool->release(Phys{r.handle[it->index], r.seq[it->index]});
       else
-        (void)hipMemRelease(r.handle[it->index]);
+        (void)vmm_try_release(r.handle[it->index]);
       r.mapped[it->index] = 0;
-      if (r.backfilled && hipMemMap(va, ps, 0, r.zero_of(it->index), 0) == hipSuccess) (void)hipMemSetAccess(va, ps, &acc, 1);
+      if (r.backfilled && vmm_try_map(va, ps, r.zero_of(it->index))) (void)vmm_try_set_access(va, ps, ctx->dev());
     }
     (void)hipGetLastError();
     try {
@@ -1050,13 +1053,12 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   u.page_size = ps;
-  const auto acc = make_rw_access(ctx->dev());
   char *run_start = nullptr;
   size_t run_len = 0;
   const size_t max_run = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
   auto flush_run = [&]() {
     if (!run_len) return;
-    HIP_CHECK(hipMemSetAccess(run_start, run_len, &acc, 1));
+    vmm_set_access(run_start, run_len, ctx->dev());
     run_len = 0;
   };
   u.own.reserve(slots.size());
@@ -1068,7 +1070,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     }
     char *va = r.base + s.index * ps;
     const int64_t t0 = now_ns();
-    HIP_CHECK(hipMemUnmap(va, ps));
+    vmm_unmap(va, ps);
     const int64_t t1 = now_ns();
     stats().t_unmap += t1 - t0;
     if (r.mapped[s.index] == 1)
@@ -1080,7 +1082,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();
-      HIP_CHECK(hipMemMap(va, ps, 0, r.zero_of(s.index), 0));
+      vmm_map(va, ps, r.zero_of(s.index));
       stats().t_realias += now_ns() - tr;
       if (!(run_len && va == run_start + run_len && run_len < max_run)) {
         flush_run();
@@ -1113,8 +1115,7 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   else
     ctx->defer_tlb_shootdown();
   for (auto h : u.imported) {
-    hipError_t st = hipMemRelease(h);
-    if (st != hipSuccess) KVC_LOG(LOG_ERROR, "hipMemRelease(imported) failed: %s", hipGetErrorString(st));
+    if (!vmm_try_release(h)) KVC_LOG(LOG_ERROR, "releasing an imported handle failed");
   }
   const int64_t tr0 = now_ns();
   pool->release_batch(u.own.data(), u.own.size());
@@ -1133,7 +1134,12 @@ std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by 
 }
 static phys_handle_t import_posix_fd(int fd) {
   if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
-  phys_handle_t h{};
+  if (vmm_backend() == kVmmHsa) { // ROCr takes the dmabuf fd by value
+    hsa_amd_vmem_alloc_handle_t hh{};
+    HSA_CHECK(hsa_amd_vmem_import_shareable_handle(fd, &hh));
+    return hh.handle;
+  }
+  hipMemGenericAllocationHandle_t h{};
   int conv = g_import_convention.load();
   if (conv != 2) {
     alignas(8) static thread_local int slot;
@@ -1141,7 +1147,7 @@ static phys_handle_t import_posix_fd(int fd) {
     hipError_t st = hipMemImportFromShareableHandle(&h, static_cast<void *>(&slot), hipMemHandleTypePosixFileDescriptor);
     if (st == hipSuccess) {
       g_import_convention = 1;
-      return h;
+      return reinterpret_cast<phys_handle_t>(h);
     }
     (void)hipGetLastError();
     int rt = 0;
@@ -1152,7 +1158,7 @@ static phys_handle_t import_posix_fd(int fd) {
   HIP_CHECK(hipMemImportFromShareableHandle(&h, reinterpret_cast<void *>(static_cast<uintptr_t>(fd)),
                                             hipMemHandleTypePosixFileDescriptor));
   g_import_convention = 2;
-  return h;
+  return reinterpret_cast<phys_handle_t>(h);
 }
 
 int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap) {
@@ -1166,7 +1172,10 @@ int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out
   for (auto &s : slots) {
     if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
     int fd = -1;
-    HIP_CHECK(hipMemExportToShareableHandle(&fd, s.region->handle[s.index], hipMemHandleTypePosixFileDescriptor, 0));
+    if (vmm_backend() == kVmmHsa)
+      HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
+    else
+      HIP_CHECK(hipMemExportToShareableHandle(&fd, as_hip(s.region->handle[s.index]), hipMemHandleTypePosixFileDescriptor, 0));
     out_fds[k++] = fd;
   }
   return k;
@@ -1184,7 +1193,7 @@ bool KvAllocator::map_imported_slots(const offset_t *offsets, size_t n, const in
   try {
     for (; i < n_fds; ++i) hs[i] = import_posix_fd(fds[i]);
   } catch (...) {
-    for (size_t j = 0; j < i; ++j) (void)hipMemRelease(hs[j]);
+    for (size_t j = 0; j < i; ++j) (void)vmm_try_release(hs[j]);
     throw;
   }
   map_slots(slots, &hs);

@@ -1,0 +1,107 @@
+"""KVCACHED_VMM_BACKEND=hsa on a real MI355X: the same allocator talking to ROCr (hsa_amd_vmem_*) instead of HIP's
+VMM API — hipMemUnmap's marker round trip through the GPU queue (10 of its 12-15 us) disappears. HIP has never heard
+of memory mapped this way: kernels, device-to-device copies, memset and pointer queries work on it, a host<->device
+hipMemcpy does not (it crashes: HIP takes the pointer for pageable host memory), and neither does torch's
+`clone()`/contiguous `copy_()`, which are hipMemcpyAsync underneath. The checks therefore run in a child process and
+look at KV memory only through kernels (`(t + 0).cpu()`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import faulthandler, json, os, sys, time
+faulthandler.enable()
+sys.path.insert(0, os.environ["KVC_REPO"]); sys.path.insert(0, os.path.join(os.environ["KVC_REPO"], "tests"))
+import numpy as np, torch
+import kvc_testlib as T
+from kvcached_amd import capi, vmm_ops
+DEV, PAGE = "cuda:0", 2 << 20
+out = {}
+
+def host(t):            # never hipMemcpy out of HSA-mapped memory (clone() is a hipMemcpy too): go through a kernel
+    return (t + 0).cpu()
+
+# ---- 1. raw allocator: zero fill, privacy, recycled handles, ledger
+vmm_ops.init_kvcached(DEV, PAGE, False)
+ts = vmm_ops.create_kv_tensors(512 * PAGE, 2, DEV, 1, 1, 0, True)
+t = ts[0]; epp = PAGE // 2
+rng = np.random.default_rng(0)
+order = [int(x) for x in rng.permutation(512)]
+capi.reset_stats()
+assert vmm_ops.map_to_kv_tensors([p * PAGE for p in order])
+v = t.view(512, epp)
+assert int(torch.count_nonzero(t)) == 0
+stamp = (torch.arange(512, device=DEV) % 251 + 1).to(torch.int16)
+v.copy_(stamp.unsqueeze(1).expand_as(v)); torch.cuda.synchronize()
+assert torch.equal(v.sum(dim=1, dtype=torch.int32), stamp.to(torch.int32) * epp)
+victims = [int(x) for x in rng.permutation(512)[:256]]
+assert vmm_ops.unmap_from_kv_tensors([p * PAGE for p in victims])
+back = [int(x) for x in rng.permutation(victims)]
+assert vmm_ops.map_to_kv_tensors([p * PAGE for p in back])           # recycled, dirty handles on other slots
+want = stamp.to(torch.int32) * epp; want[torch.as_tensor(victims, device=DEV)] = 0
+assert torch.equal(v.sum(dim=1, dtype=torch.int32), want)
+assert host(v[victims[0]][:8]).tolist() == [0] * 8
+st = capi.get_stats()
+assert st["handles_created"] == 512 and st["handles_reused"] == 256, st
+assert vmm_ops.unmap_from_kv_tensors([p * PAGE for p in range(512)])
+# per-page driver time of a warm cycle
+offs = [p * PAGE for p in order]
+for _ in range(2):
+    vmm_ops.map_to_kv_tensors(offs); vmm_ops.unmap_from_kv_tensors(offs)
+capi.reset_stats()
+t0 = time.perf_counter(); vmm_ops.map_to_kv_tensors(offs); t1 = time.perf_counter(); vmm_ops.unmap_from_kv_tensors(offs); t2 = time.perf_counter()
+drv = capi.get_driver_breakdown()
+out["us_per_page"] = {"map_call": (t1 - t0) / 512 * 1e6, "unmap_call": (t2 - t1) / 512 * 1e6,
+                      **{k: v / 1e3 / 512 for k, v in drv.items() if v}}
+# kernels of the library on such memory
+assert vmm_ops.map_to_kv_tensors([0, PAGE])
+t[:2 * epp].fill_(5); torch.cuda.synchronize()
+capi.zero_fill_pages([t.data_ptr() + PAGE], PAGE)
+assert int(torch.count_nonzero(t[epp:2 * epp])) == 0 and bool((t[:epp] == 5).all())
+assert vmm_ops.unmap_from_kv_tensors([0, PAGE])
+vmm_ops.shutdown_kvcached()
+
+# ---- 2. the reference's golden trace through KVCacheManager, every map/unmap executed with the hsa backend
+case = json.load(open(os.path.join(T.GOLDEN_DIR, "manager_large.json")))["cases"][2]
+cfg = case["config"]
+ad = T.ProductAdapter(cfg["num_blocks"], cfg["block_size"], cfg["cell_size"], cfg["num_layers"], world_size=cfg["world_size"],
+                      reserve_null_block=cfg["reserve_null_block"], num_kv_buffers=cfg["num_kv_buffers"],
+                      contiguous=cfg["contiguous"], phys_pages=cfg["phys_pages"], device=DEV, execute=True)
+try:
+    init = {"s": ad.snapshot(), "e": ad.drain_events()}
+    assert init == case["init"]
+    chain = T.chain_hash(T.replay(ad, case["ops"], full=False))
+    assert chain["final"] == case["chain"]["final"], "block tables differ from the reference with the hsa backend"
+finally:
+    ad.close()
+out["golden_trace_bit_exact"] = True
+
+# ---- 3. switching back to the HIP backend in the same process drains the pools first
+os.environ["KVCACHED_VMM_BACKEND"] = "hip"
+vmm_ops.init_kvcached(DEV, PAGE, False)
+ts = vmm_ops.create_kv_tensors(8 * PAGE, 2, DEV, 1, 1, 0, True)
+assert vmm_ops.map_to_kv_tensors([0, PAGE])
+assert int(torch.count_nonzero(ts[0][:2 * epp])) == 0
+assert ts[0][:4].cpu().tolist() == [0, 0, 0, 0]                          # HIP-mapped again: plain .cpu() works
+assert vmm_ops.unmap_from_kv_tensors([0, PAGE])
+vmm_ops.shutdown_kvcached()
+print("HSA_BACKEND_OK " + json.dumps(out))
+"""
+
+
+def test_hsa_vmm_backend_in_a_child_process():
+    env = dict(os.environ, KVC_REPO=REPO, KVCACHED_VMM_BACKEND="hsa", KVCACHED_LOG_LEVEL="ERROR",
+               KVCACHED_PAGE_PREALLOC_ENABLED="false", KVCACHED_IPC_NAME=f"kvc_hsa_{os.getpid()}")
+    out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=400)
+    line = [l for l in out.stdout.splitlines() if l.startswith("HSA_BACKEND_OK")]
+    assert out.returncode == 0 and line, (out.returncode, out.stdout[-800:], out.stderr[-2500:])
+    res = json.loads(line[-1].split(" ", 1)[1])
+    print("[hsa backend] us per 2 MiB page:", {k: round(v, 2) for k, v in res["us_per_page"].items()})
+    assert res["golden_trace_bit_exact"]
+    assert res["us_per_page"]["unmap"] < 8.0, res      # HIP's hipMemUnmap needs 12-15 us on the same hardware
