@@ -67,6 +67,27 @@ assert int(torch.count_nonzero(t[epp:2 * epp])) == 0 and bool((t[:epp] == 5).all
 assert vmm_ops.unmap_from_kv_tensors([0, PAGE])
 vmm_ops.shutdown_kvcached()
 
+# ---- 1b. shared pool: dmabuf export of a slot, import + map into a second group's VA; compat mode (aliased zero pages)
+os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+os.environ["KVCACHED_ZERO_BACKFILL"] = "true"
+vmm_ops.init_kvcached(DEV, PAGE, False)
+os.environ.pop("KVCACHED_EXPORTABLE_HANDLES"); os.environ.pop("KVCACHED_ZERO_BACKFILL")
+a = vmm_ops.create_kv_tensors(16 << 20, 2, DEV, 1, 2, 0, False)
+b = vmm_ops.create_kv_tensors(16 << 20, 2, DEV, 1, 2, 1, False)
+assert int(torch.count_nonzero(a[0])) == 0                                 # unbacked VA reads zeros through the aliases
+assert vmm_ops.map_to_kv_tensors([PAGE], 0)
+fds = capi.export_mapped_slots([PAGE], 0)
+assert len(fds) == 2
+capi.map_imported_slots([PAGE], fds, 1)
+for fd in fds:
+    os.close(fd)
+a[0][epp:epp + 16] = 4321; torch.cuda.synchronize()
+assert bool((b[0][epp:epp + 16] == 4321).all())
+assert vmm_ops.unmap_from_kv_tensors([PAGE], 1) and vmm_ops.unmap_from_kv_tensors([PAGE], 0)
+assert int(torch.count_nonzero(a[0])) == 0                                 # back on the zero page
+vmm_ops.shutdown_kvcached()
+out["export_import_and_compat"] = True
+
 # ---- 2. the reference's golden trace through KVCacheManager, every map/unmap executed with the hsa backend
 case = json.load(open(os.path.join(T.GOLDEN_DIR, "manager_large.json")))["cases"][2]
 cfg = case["config"]
@@ -103,5 +124,5 @@ def test_hsa_vmm_backend_in_a_child_process():
     assert out.returncode == 0 and line, (out.returncode, out.stdout[-800:], out.stderr[-2500:])
     res = json.loads(line[-1].split(" ", 1)[1])
     print("[hsa backend] us per 2 MiB page:", {k: round(v, 2) for k, v in res["us_per_page"].items()})
-    assert res["golden_trace_bit_exact"]
+    assert res["golden_trace_bit_exact"] and res["export_import_and_compat"]
     assert res["us_per_page"]["unmap"] < 8.0, res      # HIP's hipMemUnmap needs 12-15 us on the same hardware
