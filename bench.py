@@ -75,7 +75,8 @@ class Pool:
     def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
                  compound_layers: int = 0, backend: str = "hip"):
         self.capi, self.device, self.window = capi, device, window_batches
-        os.environ["KVCACHED_VMM_BACKEND"] = backend
+        os.environ["KVCACHED_VMM_BACKEND"] = "hsa" if backend.startswith("hsa") else "hip"
+        os.environ["KVCACHED_HSA_CPU_ACCESS"] = "false" if backend == "hsa_kernels_only" else "true"
         os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
         if pool_mb is not None:
             os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
@@ -98,6 +99,7 @@ class Pool:
     def close(self):
         self.capi.shutdown()
         os.environ["KVCACHED_VMM_BACKEND"] = "hip"
+        os.environ.pop("KVCACHED_HSA_CPU_ACCESS", None)
 
 
 def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
@@ -442,6 +444,7 @@ def main():
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
                         ("hsa_vmm_backend_opt_in", "lazy", None, 0, False, True),
+                        ("hsa_vmm_backend_kernels_only", "lazy", None, 0, False, True),
                         ("hsa_growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),
                         ("hsa_no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
                         ("hsa_compat_zero_backfill_sharded", "compat", None, 0, False, True),
@@ -451,9 +454,9 @@ def main():
                         ("compat_zero_backfill_sharded", "compat", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
-                        nsteps = 24 if (burst or name.startswith("fresh_va") or name == "hsa_vmm_backend_opt_in") else 8
+                        nsteps = 24 if (burst or name.startswith("fresh_va") or name.startswith("hsa_vmm_backend")) else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
-                                     backend="hsa" if name.startswith("hsa_") else "hip")
+                                     backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_") else "hip")
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
                                           for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",

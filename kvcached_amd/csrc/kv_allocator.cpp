@@ -397,6 +397,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     if (want != vmm_backend().load())
       for (auto &kv : g_contexts) kv.second->drain_pools(); // pooled handles belong to the backend that made them
     vmm_backend() = want;
+    hsa_cpu_access() = env_bool("KVCACHED_HSA_CPU_ACCESS", true) ? 1 : 0;
   }
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));

@@ -38,7 +38,8 @@ static double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static hsa_agent_t g_gpu;
+static hsa_agent_t g_gpu, g_cpu;
+static bool g_have_cpu = false;
 static hsa_amd_memory_pool_t g_pool;
 static bool g_have_gpu = false, g_have_pool = false;
 
@@ -48,6 +49,10 @@ static hsa_status_t on_agent(hsa_agent_t a, void *) {
   if (t == HSA_DEVICE_TYPE_GPU && !g_have_gpu) {
     g_gpu = a;
     g_have_gpu = true;
+  }
+  if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) {
+    g_cpu = a;
+    g_have_cpu = true;
   }
   return HSA_STATUS_SUCCESS;
 }
@@ -77,7 +82,8 @@ __global__ void count_ne(const unsigned *p, size_t n, unsigned want, unsigned lo
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1024;
   const bool hip_reserve = argc > 2 && argv[2][0] == 'h' && argv[2][1] == 'i'; // VA range reserved through HIP (so HIP knows the range)
-  const int op = argc > 3 ? atoi(argv[3]) : -1;                                 // which HIP call to try on the HSA-mapped pointer (each may crash)
+  const int op = argc > 3 ? atoi(argv[3]) : -1;
+  const bool cpu_access = argc > 4; // also grant the CPU agent access: is the pointer then a usable host pointer for HIP's fallback?                                 // which HIP call to try on the HSA-mapped pointer (each may crash)
   const size_t PAGE = 2u << 20;
   CK(hipSetDevice(0));
   CK(hipFree(nullptr)); // HIP has initialised ROCr; hsa_init only adds a reference
@@ -102,19 +108,20 @@ int main(int argc, char **argv) {
   char *va = (char *)va0;
   std::vector<hsa_amd_vmem_alloc_handle_t> h(n);
   hsa_amd_memory_access_desc_t acc{HSA_ACCESS_PERMISSION_RW, g_gpu};
+  hsa_amd_memory_access_desc_t both[2] = {{HSA_ACCESS_PERMISSION_RW, g_gpu}, {HSA_ACCESS_PERMISSION_RW, g_cpu}};
   unsigned long long *cnt;
   CK(hipMalloc(&cnt, 8));
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 
-  for (int round = 0; round < (op < 0 ? 3 : 0); round++) {
+  for (int round = 0; round < (op < 0 || op == 99 ? 3 : 0); round++) {
     double a = now_us();
     if (round == 0)
       for (int i = 0; i < n; i++) HK(hsa_amd_vmem_handle_create(g_pool, PAGE, MEMORY_TYPE_PINNED, 0, &h[i]));
     double b = now_us();
     for (int i = 0; i < n; i++) HK(hsa_amd_vmem_map(va + (size_t)i * PAGE, PAGE, 0, h[(i + round * 7) % n], 0));
     double c = now_us();
-    for (int i = 0; i < n; i++) HK(hsa_amd_vmem_set_access(va + (size_t)i * PAGE, PAGE, &acc, 1));
+    for (int i = 0; i < n; i++) HK(hsa_amd_vmem_set_access(va + (size_t)i * PAGE, PAGE, cpu_access ? both : &acc, cpu_access ? 2 : 1));
     double d = now_us();
     // HIP kernels on memory HIP has never heard of
     const unsigned stamp = 0x1000u + round;
@@ -133,10 +140,17 @@ int main(int argc, char **argv) {
   }
 
   // what HIP's copy/memset/query paths do with such a pointer
-  if (op >= 0)
+  if (op >= 0 && op != 99)
     for (int i = 0; i < n; i++) HK(hsa_amd_vmem_handle_create(g_pool, PAGE, MEMORY_TYPE_PINNED, 0, &h[i]));
   HK(hsa_amd_vmem_map(va, PAGE, 0, h[0], 0));
-  HK(hsa_amd_vmem_set_access(va, PAGE, &acc, 1));
+  if (cpu_access) {
+    double ta = now_us();
+    hsa_status_t sa = hsa_amd_vmem_set_access(va, PAGE, both, 2);
+    printf("set_access(GPU+CPU): 0x%x in %.1f us\n", (unsigned)sa, now_us() - ta);
+    if (sa != HSA_STATUS_SUCCESS) HK(hsa_amd_vmem_set_access(va, PAGE, &acc, 1));
+  } else {
+    HK(hsa_amd_vmem_set_access(va, PAGE, &acc, 1));
+  }
   fill32<<<256, 256, 0, s>>>((unsigned *)va, PAGE / 4, 0xabcd1234u);
   CK(hipStreamSynchronize(s));
   unsigned host[4] = {0, 0, 0, 0};
@@ -155,6 +169,34 @@ int main(int argc, char **argv) {
   case 4: st = hipPointerGetAttributes(&at, va); printf("hipPointerGetAttributes: %s (type %d device %d)\n", hipGetErrorString(st), (int)at.type, at.device); break;
   case 5: st = hipMemcpy(dbuf, va, 4096, hipMemcpyDeviceToDevice); printf("hipMemcpy D2D out of it: %s\n", hipGetErrorString(st)); break;
   case 6: st = hipMemcpyAsync(host, va, sizeof host, hipMemcpyDeviceToHost, s); CK(hipStreamSynchronize(s)); printf("hipMemcpyAsync D2H: %s, read 0x%x\n", hipGetErrorString(st), host[0]); break;
+  case 7: { // coherence of HIP's host-side fallback: GPU rewrites, host re-reads the same words, many times
+    int stale = 0;
+    for (unsigned it = 1; it <= 200; ++it) {
+      fill32<<<256, 256, 0, s>>>((unsigned *)va, PAGE / 4, 0x5000u + it);
+      CK(hipStreamSynchronize(s));
+      CK(hipMemcpy(host, va + (it % 7) * 4096, sizeof host, hipMemcpyDeviceToHost));
+      if (host[0] != 0x5000u + it) ++stale;
+      unsigned w[4] = {it, it, it, it}; // and the other way round: host writes, a kernel reads
+      CK(hipMemcpy(va + 8192, w, sizeof w, hipMemcpyHostToDevice));
+      CK(hipMemsetAsync(cnt, 0, 8, s));
+      count_ne<<<1, 4, 0, s>>>((const unsigned *)(va + 8192), 4, it, cnt);
+      unsigned long long bad = 0;
+      CK(hipMemcpyAsync(&bad, cnt, 8, hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      if (bad) ++stale;
+    }
+    printf("coherence: %d stale observations in 200 rewrite/re-read rounds\n", stale);
+    std::vector<char> big(64u << 20);
+    for (int k = 0; k < 32; k++) { HK(hsa_amd_vmem_map(va + (size_t)(k + 1) * PAGE, PAGE, 0, h[k + 1], 0)); HK(hsa_amd_vmem_set_access(va + (size_t)(k + 1) * PAGE, PAGE, both, 2)); }
+    double ta = now_us();
+    CK(hipMemcpy(big.data(), va + PAGE, 32 * PAGE, hipMemcpyDeviceToHost));
+    double tb = now_us();
+    CK(hipMemcpy(va + PAGE, big.data(), 32 * PAGE, hipMemcpyHostToDevice));
+    double tc = now_us();
+    printf("64 MiB through HIP's host fallback: D2H %.1f MB/s, H2D %.1f MB/s\n", 64.0 * 1.048576 / ((tb - ta) * 1e-6), 64.0 * 1.048576 / ((tc - tb) * 1e-6));
+    for (int k = 0; k < 32; k++) HK(hsa_amd_vmem_unmap(va + (size_t)(k + 1) * PAGE, PAGE));
+    break;
+  }
   default: printf("no op\n");
   }
   fflush(stdout);

@@ -1,9 +1,9 @@
 """KVCACHED_VMM_BACKEND=hsa on a real MI355X: the same allocator talking to ROCr (hsa_amd_vmem_*) instead of HIP's
 VMM API — hipMemUnmap's marker round trip through the GPU queue (10 of its 12-15 us) disappears. HIP has never heard
-of memory mapped this way: kernels, device-to-device copies, memset and pointer queries work on it, a host<->device
-hipMemcpy does not (it crashes: HIP takes the pointer for pageable host memory), and neither does torch's
-`clone()`/contiguous `copy_()`, which are hipMemcpyAsync underneath. The checks therefore run in a child process and
-look at KV memory only through kernels (`(t + 0).cpu()`)."""
+of memory mapped this way and takes such a pointer for pageable host memory in hipMemcpy (torch's `.cpu()`, `clone()`,
+contiguous `copy_()`). With KVCACHED_HSA_CPU_ACCESS=true (default) the mappings are CPU-accessible too, so that
+fallback works (slowly: it reads through the PCIe BAR); with it off HIP would crash there and only kernels may touch
+the memory. Runs in a child process; bulk checks look at KV memory through kernels (`(t + 0).cpu()`)."""
 import json
 import os
 import subprocess
@@ -47,18 +47,32 @@ assert vmm_ops.map_to_kv_tensors([p * PAGE for p in back])           # recycled,
 want = stamp.to(torch.int32) * epp; want[torch.as_tensor(victims, device=DEV)] = 0
 assert torch.equal(v.sum(dim=1, dtype=torch.int32), want)
 assert host(v[victims[0]][:8]).tolist() == [0] * 8
+# a plain device->host hipMemcpy on such a pointer: with the mappings CPU-accessible HIP either copies through its
+# host-memory fallback (ROCm 7.2 runtime) or rejects the call (the runtime bundled with PyTorch 2.10: invalid
+# argument) - it must not crash
+try:
+    got = v[victims[0]][:8].cpu().tolist()
+    assert got == [0] * 8
+    out["plain_d2h"] = "works"
+except RuntimeError as e:
+    out["plain_d2h"] = "raises: " + str(e).splitlines()[0][:60]
+    try:
+        torch.cuda.synchronize()
+    except RuntimeError:
+        pass
 st = capi.get_stats()
 assert st["handles_created"] == 512 and st["handles_reused"] == 256, st
 assert vmm_ops.unmap_from_kv_tensors([p * PAGE for p in range(512)])
-# per-page driver time of a warm cycle
+# per-page driver time of a warm cycle, with the mappings CPU-accessible (default) ...
 offs = [p * PAGE for p in order]
-for _ in range(2):
-    vmm_ops.map_to_kv_tensors(offs); vmm_ops.unmap_from_kv_tensors(offs)
-capi.reset_stats()
-t0 = time.perf_counter(); vmm_ops.map_to_kv_tensors(offs); t1 = time.perf_counter(); vmm_ops.unmap_from_kv_tensors(offs); t2 = time.perf_counter()
-drv = capi.get_driver_breakdown()
-out["us_per_page"] = {"map_call": (t1 - t0) / 512 * 1e6, "unmap_call": (t2 - t1) / 512 * 1e6,
-                      **{k: v / 1e3 / 512 for k, v in drv.items() if v}}
+def cycle_cost():
+    for _ in range(2):
+        vmm_ops.map_to_kv_tensors(offs); vmm_ops.unmap_from_kv_tensors(offs)
+    capi.reset_stats()
+    t0 = time.perf_counter(); vmm_ops.map_to_kv_tensors(offs); t1 = time.perf_counter(); vmm_ops.unmap_from_kv_tensors(offs); t2 = time.perf_counter()
+    drv = capi.get_driver_breakdown()
+    return {"map_call": (t1 - t0) / 512 * 1e6, "unmap_call": (t2 - t1) / 512 * 1e6, **{k: v / 1e3 / 512 for k, v in drv.items() if v}}
+out["us_per_page"] = cycle_cost()
 # kernels of the library on such memory
 assert vmm_ops.map_to_kv_tensors([0, PAGE])
 t[:2 * epp].fill_(5); torch.cuda.synchronize()
@@ -66,6 +80,14 @@ capi.zero_fill_pages([t.data_ptr() + PAGE], PAGE)
 assert int(torch.count_nonzero(t[epp:2 * epp])) == 0 and bool((t[:epp] == 5).all())
 assert vmm_ops.unmap_from_kv_tensors([0, PAGE])
 vmm_ops.shutdown_kvcached()
+# ... and kernels-only (KVCACHED_HSA_CPU_ACCESS=false)
+os.environ["KVCACHED_HSA_CPU_ACCESS"] = "false"
+vmm_ops.init_kvcached(DEV, PAGE, False)
+ts2 = vmm_ops.create_kv_tensors(512 * PAGE, 2, DEV, 1, 1, 0, True)
+out["us_per_page_kernels_only"] = cycle_cost()
+assert vmm_ops.map_to_kv_tensors([0]); assert int(torch.count_nonzero(ts2[0][:epp])) == 0; assert vmm_ops.unmap_from_kv_tensors([0])
+vmm_ops.shutdown_kvcached()
+os.environ.pop("KVCACHED_HSA_CPU_ACCESS")
 
 # ---- 1b. shared pool: dmabuf export of a slot, import + map into a second group's VA; compat mode (aliased zero pages)
 os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
@@ -123,6 +145,9 @@ def test_hsa_vmm_backend_in_a_child_process():
     line = [l for l in out.stdout.splitlines() if l.startswith("HSA_BACKEND_OK")]
     assert out.returncode == 0 and line, (out.returncode, out.stdout[-800:], out.stderr[-2500:])
     res = json.loads(line[-1].split(" ", 1)[1])
+    print("[hsa backend] plain .cpu() on HSA-mapped KV memory:", res["plain_d2h"])
     print("[hsa backend] us per 2 MiB page:", {k: round(v, 2) for k, v in res["us_per_page"].items()})
+    print("[hsa backend, kernels only] us per 2 MiB page:", {k: round(v, 2) for k, v in res["us_per_page_kernels_only"].items()})
+    assert res["us_per_page_kernels_only"]["unmap"] < res["us_per_page"]["unmap"] + 1.0
     assert res["golden_trace_bit_exact"] and res["export_import_and_compat"]
     assert res["us_per_page"]["unmap"] < 8.0, res      # HIP's hipMemUnmap needs 12-15 us on the same hardware
