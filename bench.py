@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["hip", "hybrid", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "hybrid"),
+                    help="VMM backend of the main measurement (DESIGN.md §4.6)")
     return ap.parse_args()
 
 
@@ -73,9 +75,9 @@ class Pool:
     """One region of `window` batches, driven through the C ABI."""
 
     def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
-                 compound_layers: int = 0, backend: str = "hip"):
+                 compound_layers: int = 0, backend: str = "hybrid"):
         self.capi, self.device, self.window = capi, device, window_batches
-        os.environ["KVCACHED_VMM_BACKEND"] = "hsa" if backend.startswith("hsa") else "hip"
+        os.environ["KVCACHED_VMM_BACKEND"] = "hsa" if backend.startswith("hsa") else backend
         os.environ["KVCACHED_HSA_CPU_ACCESS"] = "false" if backend == "hsa_kernels_only" else "true"
         os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
         if pool_mb is not None:
@@ -98,7 +100,7 @@ class Pool:
 
     def close(self):
         self.capi.shutdown()
-        os.environ["KVCACHED_VMM_BACKEND"] = "hip"
+        os.environ.pop("KVCACHED_VMM_BACKEND", None)
         os.environ.pop("KVCACHED_HSA_CPU_ACCESS", None)
 
 
@@ -114,7 +116,7 @@ def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
 
 
 def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0,
-            burst=False, prefault=True, backend="hip"):
+            burst=False, prefault=True, backend="hybrid"):
     """cycle (default): every step maps+zeroes one batch and unmaps it again. burst=True: `steps` batches are
     backed one after the other and only unmapped after the timed region.
     prefault: as in the bench_vmm protocol (warm-up sweeps over the whole window before the timed sweeps), every batch
@@ -398,7 +400,7 @@ def main():
         fanout = CollectiveFanout(device=device if backend == "nccl" else "cpu")
         barrier = dist.barrier
 
-    res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync)
+    res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync, backend=args.backend)
     elapsed = res["elapsed"]
     if use_dist:
         import torch.distributed as dist
@@ -425,7 +427,7 @@ def main():
             "config": {"workload": "bench_vmm: 64 GiB VA window (one untimed warm-up sweep over the window during set-up, as in "
                                    "the protocol); step = map+zero then unmap one batch of 1024 x 2 MiB "
                                    "pages (shuffled offsets), both halves timed",
-                       "mode": args.mode, "page_MiB": 2, "batch_pages": BATCH_PAGES,
+                       "mode": args.mode, "vmm_backend": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
             "map_zero_GBps": round(main_sum["map_zero_GBps"], 2),
@@ -443,20 +445,20 @@ def main():
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
-                        ("hsa_vmm_backend_opt_in", "lazy", None, 0, False, True),
-                        ("hsa_vmm_backend_kernels_only", "lazy", None, 0, False, True),
-                        ("hsa_growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),
-                        ("hsa_no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
-                        ("hsa_compat_zero_backfill_sharded", "compat", None, 0, False, True),
+                        ("hip_backend_same_cycle", "lazy", None, 0, False, True),
+                        ("hip_backend_compat_zero_backfill_sharded", "compat", None, 0, False, True),
+                        ("hsa_backend_cpu_accessible", "lazy", None, 0, False, True),
+                        ("hsa_backend_kernels_only", "lazy", None, 0, False, True),
                         ("fresh_va_window_warm_process", "lazy", None, 0, False, False),
                         ("growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),   # growth = fresh VA, fresh handles
                         ("no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
                         ("compat_zero_backfill_sharded", "compat", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
-                        nsteps = 24 if (burst or name.startswith("fresh_va") or name.startswith("hsa_vmm_backend")) else 8
+                        nsteps = 24 if (burst or name.startswith("fresh_va") or name == "hip_backend_same_cycle") else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
-                                     backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_") else "hip")
+                                     backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
+                                     else ("hip" if name.startswith("hip_") else args.backend))
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
                                           for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",

@@ -59,11 +59,16 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 // works on the KV tensors), KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only.
 using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer) or hsa_amd_vmem_alloc_handle_t::handle
 
-enum : int { kVmmHip = 0, kVmmHsa = 1 };
+enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2 };
+// kVmmHybrid: VA reserved through HIP and every slot registered with HIP once (hipMemMap of a placeholder handle,
+// taken away again through ROCr at once); from then on the slot is backed and unbacked with hsa_amd_vmem_* only.
+// HIP keeps resolving the pointer (its copies use the VA, the hardware walks the page tables ROCr wrote): every
+// hipMemcpy flavour works at full speed, and map/unmap run at ROCr's speed. See KvAllocator::register_slot.
 inline std::atomic<int> &vmm_backend() { // set by KvAllocator::init from KVCACHED_VMM_BACKEND; fixed while handles exist
   static std::atomic<int> v{kVmmHip};
   return v;
 }
+inline bool vmm_uses_rocr() { return vmm_backend().load() != kVmmHip; }
 
 inline void hsa_check(hsa_status_t st, const char *tok, const char *file, int line) {
   if (st == HSA_STATUS_SUCCESS) return;
@@ -180,7 +185,7 @@ inline hsa_amd_vmem_alloc_handle_t as_hsa(phys_handle_t h) { return hsa_amd_vmem
 // ---- the VMM verbs, in a throwing form (vmm_*) and a quiet one for cleanup / rollback paths (vmm_try_*)
 inline void *vmm_reserve(size_t size, size_t align, void *hint) {
   void *p = nullptr;
-  if (vmm_backend() == kVmmHsa)
+  if (vmm_backend() == kVmmHsa) // hybrid: through HIP, so that HIP knows the range
     HSA_CHECK(hsa_amd_vmem_address_reserve_align(&p, size, reinterpret_cast<uint64_t>(hint), align, 0));
   else
     HIP_CHECK(hipMemAddressReserve(&p, size, align, hint, 0));
@@ -191,7 +196,7 @@ inline bool vmm_try_address_free(void *va, size_t size) {
   return hipMemAddressFree(va, size) == hipSuccess;
 }
 inline phys_handle_t vmm_create(int dev, size_t size, bool exportable) {
-  if (vmm_backend() == kVmmHsa) {
+  if (vmm_uses_rocr()) {
     hsa_amd_vmem_alloc_handle_t h{};
     HSA_CHECK(hsa_amd_vmem_handle_create(hsa_device(dev).pool, size, MEMORY_TYPE_PINNED, 0, &h));
     return h.handle;
@@ -202,21 +207,21 @@ inline phys_handle_t vmm_create(int dev, size_t size, bool exportable) {
   return reinterpret_cast<phys_handle_t>(h);
 }
 inline bool vmm_try_release(phys_handle_t h) {
-  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
+  if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }
 inline void vmm_map(void *va, size_t size, phys_handle_t h) {
-  if (vmm_backend() == kVmmHsa)
+  if (vmm_uses_rocr())
     HSA_CHECK(hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0));
   else
     HIP_CHECK(hipMemMap(va, size, 0, as_hip(h), 0));
 }
 inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
-  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
+  if (vmm_uses_rocr()) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
   return hipMemMap(va, size, 0, as_hip(h), 0) == hipSuccess;
 }
 inline void vmm_set_access(void *va, size_t size, int dev) {
-  if (vmm_backend() == kVmmHsa) {
+  if (vmm_uses_rocr()) {
     const HsaDevice &hd = hsa_device(dev);
     hsa_amd_memory_access_desc_t d[2] = {{HSA_ACCESS_PERMISSION_RW, hd.agent}, {HSA_ACCESS_PERMISSION_RW, hd.cpu}};
     HSA_CHECK(hsa_amd_vmem_set_access(va, size, d, hsa_cpu_access().load() && hd.have_cpu ? 2 : 1));
@@ -226,7 +231,7 @@ inline void vmm_set_access(void *va, size_t size, int dev) {
   }
 }
 inline bool vmm_try_set_access(void *va, size_t size, int dev) {
-  if (vmm_backend() == kVmmHsa) {
+  if (vmm_uses_rocr()) {
     try {
       const HsaDevice &hd = hsa_device(dev);
       hsa_amd_memory_access_desc_t d[2] = {{HSA_ACCESS_PERMISSION_RW, hd.agent}, {HSA_ACCESS_PERMISSION_RW, hd.cpu}};
@@ -239,13 +244,13 @@ inline bool vmm_try_set_access(void *va, size_t size, int dev) {
   return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
 }
 inline void vmm_unmap(void *va, size_t size) {
-  if (vmm_backend() == kVmmHsa)
+  if (vmm_uses_rocr())
     HSA_CHECK(hsa_amd_vmem_unmap(va, size));
   else
     HIP_CHECK(hipMemUnmap(va, size));
 }
 inline bool vmm_try_unmap(void *va, size_t size) {
-  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
+  if (vmm_uses_rocr()) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
   const bool ok = hipMemUnmap(va, size) == hipSuccess;
   if (!ok) (void)hipGetLastError();
   return ok;

@@ -361,6 +361,65 @@ void GpuContext::sync(hipStream_t s) {
   harvest();
 }
 
+// The hybrid backend rests on one property of the HIP runtime: once it has recorded a mapping for a VA it keeps
+// addressing that VA in copies and memsets, whatever ROCr has mapped there since. Checked once per init on a
+// scratch page (a few hundred microseconds): placeholder mapped through HIP and removed through ROCr, a real page
+// mapped through ROCr, written with hipMemset and read back with hipMemcpy. Any surprise -> the plain HIP backend.
+namespace {
+bool hybrid_self_test(int dev) {
+  const size_t ps = kBasePage;
+  void *va = nullptr;
+  hipMemGenericAllocationHandle_t shell = nullptr;
+  hsa_amd_vmem_alloc_handle_t real{};
+  bool have_real = false, hip_mapped = false, rocr_mapped = false, ok = false;
+  try {
+    const HsaDevice &hd = hsa_device(dev);
+    auto prop = make_alloc_prop(dev, false);
+    if (hipMemAddressReserve(&va, ps, ps, nullptr, 0) != hipSuccess) throw 1;
+    if (hipMemCreate(&shell, ps, &prop, 0) != hipSuccess) throw 2;
+    if (hipMemMap(va, ps, 0, shell, 0) != hipSuccess) throw 3;
+    hip_mapped = true;
+    if (hsa_amd_vmem_unmap(va, ps) != HSA_STATUS_SUCCESS) throw 4;
+    if (hsa_amd_vmem_handle_create(hd.pool, ps, MEMORY_TYPE_PINNED, 0, &real) != HSA_STATUS_SUCCESS) throw 5;
+    have_real = true;
+    if (hsa_amd_vmem_map(va, ps, 0, real, 0) != HSA_STATUS_SUCCESS) throw 6;
+    rocr_mapped = true;
+    hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hd.agent};
+    if (hsa_amd_vmem_set_access(va, ps, &d, 1) != HSA_STATUS_SUCCESS) throw 7;
+    unsigned char host[256];
+    memset(host, 0, sizeof host);
+    if (hipMemset(va, 0x5a, sizeof host) != hipSuccess) throw 8;
+    if (hipMemcpy(host, va, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) throw 9;
+    for (unsigned char c : host)
+      if (c != 0x5a) throw 10;
+    memset(host, 0xc3, sizeof host);
+    if (hipMemcpy(static_cast<char *>(va) + 4096, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) throw 11;
+    unsigned char back[256];
+    if (hipMemcpy(back, static_cast<char *>(va) + 4096, sizeof back, hipMemcpyDeviceToHost) != hipSuccess) throw 12;
+    if (memcmp(back, host, sizeof back) != 0) throw 13;
+    ok = true;
+  } catch (int step) {
+    KVC_LOG(LOG_WARNING, "hybrid VMM self test stopped at step %d", step);
+  } catch (const std::exception &e) {
+    KVC_LOG(LOG_WARNING, "hybrid VMM self test: %s", e.what());
+  }
+  (void)hipGetLastError();
+  // teardown in the order HIP expects: something mapped at the VA, HIP unmaps it
+  if (hip_mapped) {
+    if (!rocr_mapped && have_real) rocr_mapped = hsa_amd_vmem_map(va, ps, 0, real, 0) == HSA_STATUS_SUCCESS;
+    if (hipMemUnmap(va, ps) != hipSuccess) {
+      (void)hipGetLastError();
+      if (rocr_mapped) (void)hsa_amd_vmem_unmap(va, ps);
+    }
+  }
+  if (have_real) (void)hsa_amd_vmem_handle_release(real);
+  if (shell) (void)hipMemRelease(shell);
+  if (va) (void)hipMemAddressFree(va, ps);
+  (void)hipGetLastError();
+  return ok;
+}
+} // namespace
+
 // ------------------------------------------------------------------ registry
 void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contiguous_layout) {
   std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> old; // destroyed after g_mu is released
@@ -391,13 +450,13 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
-    const std::string b = be ? be : "hip";
-    if (b != "hip" && b != "hsa") throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip' or 'hsa'");
-    const int want = b == "hsa" ? kVmmHsa : kVmmHip;
+    const std::string b = be ? be : "hybrid";
+    if (b != "hip" && b != "hsa" && b != "hybrid") throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip', 'hybrid' or 'hsa'");
+    const int want = b == "hsa" ? kVmmHsa : (b == "hybrid" ? kVmmHybrid : kVmmHip);
     if (want != vmm_backend().load())
       for (auto &kv : g_contexts) kv.second->drain_pools(); // pooled handles belong to the backend that made them
     vmm_backend() = want;
-    hsa_cpu_access() = env_bool("KVCACHED_HSA_CPU_ACCESS", true) ? 1 : 0;
+    hsa_cpu_access() = (want == kVmmHsa && env_bool("KVCACHED_HSA_CPU_ACCESS", true)) ? 1 : 0; // hybrid: HIP resolves the pointers itself
   }
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
@@ -408,6 +467,11 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     HIP_CHECK(hipInit(0));
     g_device.index = resolve_dev_index(g_device);
     context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
+    if (vmm_backend() == kVmmHybrid && !hybrid_self_test(g_device.index)) {
+      KVC_LOG(LOG_WARNING, "hybrid VMM backend failed its self test on this HIP runtime: using the plain HIP backend "
+                           "(KVCACHED_VMM_BACKEND=hip), map/unmap will be ~2x slower");
+      vmm_backend() = kVmmHip;
+    }
   }
   g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout,
                                                   g_device.is_gpu ? context_for(g_device.index) : nullptr);
@@ -608,6 +672,7 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
   r->handle.assign(r->num_slots(), phys_handle_t{});
   r->seq.assign(r->num_slots(), 0);
   r->mapped.assign(r->num_slots(), 0);
+  r->registered.assign(r->num_slots(), 0);
   return r;
 }
 
@@ -624,8 +689,10 @@ void KvAllocator::backfill_all(KvRegion &r) {
   try {
     for (; made < n_zero; ++made) r.zero[made] = vmm_create(ctx_->dev(), r.page_size, false);
     const size_t run = (size_t)std::max<int64_t>(1, options().access_run_slots.load());
-    for (size_t i = 0; i < r.num_slots(); ++i)
+    for (size_t i = 0; i < r.num_slots(); ++i) {
+      if (vmm_backend() == kVmmHybrid) register_slot(r, i); // compat promises zeros to ANY access, hipMemcpy included
       vmm_map(r.base + i * r.page_size, r.page_size, r.zero_of(i));
+    }
     for (size_t i = 0; i < r.num_slots(); i += run) {
       size_t k = std::min(run, r.num_slots() - i);
       vmm_set_access(r.base + i * r.page_size, k * r.page_size, ctx_->dev());
@@ -647,6 +714,63 @@ void KvAllocator::backfill_all(KvRegion &r) {
   ctx_->sync(nullptr);
 }
 
+// Hybrid backend. HIP resolves a device pointer through its own table of allocations and mappings; a VA that only
+// ROCr knows is "pageable host memory" to hipMemcpy. So each slot is introduced to HIP once: hipMemMap of a placeholder
+// handle at the slot's VA (HIP records VA -> memory object), then hsa_amd_vmem_unmap of that very mapping (ROCr's
+// state: nothing mapped; HIP never looks again). Every later backing of the slot goes through ROCr only. HIP's copy
+// engines address memory by VA and the hardware walks the page tables ROCr maintains, so all hipMemcpy flavours keep
+// working, at full speed (tools/hsa_vmm_probe.cpp op 8: D2H 32-50 GB/s, 0 wrong words over re-backing rounds).
+// One placeholder per `fanout` slots (as for the zero pages) keeps the number of mappings HIP hangs off one handle
+// small. Cost: hipMemMap 3 us + unmap 3 us, once per slot per region lifetime.
+void KvAllocator::register_slot(KvRegion &r, size_t slot) {
+  if (r.registered[slot]) return;
+  constexpr size_t kShellFanout = 4096; // slots per placeholder handle: <= 72 MiB of placeholders for 288 GiB of 2 MiB slots
+  const size_t shard = slot / kShellFanout;
+  if (r.shell.size() <= shard) r.shell.resize(shard + 1, nullptr);
+  if (!r.shell[shard]) {
+    auto prop = make_alloc_prop(ctx_->dev(), false);
+    HIP_CHECK(hipMemCreate(&r.shell[shard], r.page_size, &prop, 0));
+  }
+  char *va = r.base + slot * r.page_size;
+  HIP_CHECK(hipMemMap(va, r.page_size, 0, r.shell[shard], 0));
+  HSA_CHECK(hsa_amd_vmem_unmap(va, r.page_size));
+  r.registered[slot] = 1;
+}
+
+// Teardown of the above: HIP believes its placeholder mappings are still there and must be allowed to unmap them
+// (hipMemAddressFree and hipMemRelease expect that). Whatever ROCr has at the VA - our page, or a stand-in mapped
+// for the occasion - is what HIP's unmap removes.
+void KvAllocator::unregister_slots(KvRegion &r) {
+  hsa_amd_vmem_alloc_handle_t standin{};
+  bool have_standin = false;
+  size_t failures = 0;
+  for (size_t i = 0; i < r.num_slots(); ++i) {
+    if (!r.registered[i]) continue;
+    char *va = r.base + i * r.page_size;
+    if (!r.mapped[i] && !r.backfilled) { // nothing at the VA on ROCr's side (in compat mode a zero alias is): give HIP something to unmap
+      if (!have_standin) {
+        have_standin = hsa_amd_vmem_handle_create(hsa_device(ctx_->dev()).pool, r.page_size, MEMORY_TYPE_PINNED, 0, &standin) ==
+                       HSA_STATUS_SUCCESS;
+      }
+      if (!have_standin || hsa_amd_vmem_map(va, r.page_size, 0, standin, 0) != HSA_STATUS_SUCCESS) {
+        ++failures;
+        continue;
+      }
+    }
+    if (hipMemUnmap(va, r.page_size) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hsa_amd_vmem_unmap(va, r.page_size);
+      ++failures;
+    }
+    r.registered[i] = 0;
+  }
+  if (have_standin) (void)hsa_amd_vmem_handle_release(standin);
+  for (auto h : r.shell)
+    if (h && hipMemRelease(h) != hipSuccess) (void)hipGetLastError();
+  r.shell.clear();
+  if (failures) KVC_LOG(LOG_ERROR, "%zu slots of %s could not be unregistered from HIP", failures, r.name.c_str());
+}
+
 void KvAllocator::destroy_region(KvRegion &r) {
   if (!r.base) return;
   if (!r.on_gpu) {
@@ -658,7 +782,12 @@ void KvAllocator::destroy_region(KvRegion &r) {
   if (ctx) (void)hipSetDevice(ctx->dev());
   // Tolerate stale mappings during teardown: log, do not throw (ftensor.cpp:78-98).
   bool whole = false;
-  if (r.backfilled) {
+  if (vmm_backend() == kVmmHybrid) {
+    // HIP unmaps every slot it was told about (that removes our pages' and aliases' mappings too); what was never
+    // registered cannot be mapped either
+    unregister_slots(r);
+    whole = true;
+  } else if (r.backfilled) {
     whole = vmm_try_unmap(r.base, r.size);
     if (!whole) KVC_LOG(LOG_ERROR, "unmapping the whole region %s in one call failed", r.name.c_str());
   }
@@ -958,6 +1087,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
+      if (vmm_backend() == kVmmHybrid && !r.registered[s.index]) register_slot(r, s.index); // once per slot
       if (r.backfilled) vmm_unmap(va, ps);
       int64_t t1 = now_ns();
       bool recycled = false;
@@ -1135,7 +1265,7 @@ std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by 
 }
 static phys_handle_t import_posix_fd(int fd) {
   if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
-  if (vmm_backend() == kVmmHsa) { // ROCr takes the dmabuf fd by value
+  if (vmm_uses_rocr()) { // ROCr takes the dmabuf fd by value
     hsa_amd_vmem_alloc_handle_t hh{};
     HSA_CHECK(hsa_amd_vmem_import_shareable_handle(fd, &hh));
     return hh.handle;
@@ -1173,7 +1303,7 @@ int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out
   for (auto &s : slots) {
     if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
     int fd = -1;
-    if (vmm_backend() == kVmmHsa)
+    if (vmm_uses_rocr())
       HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
     else
       HIP_CHECK(hipMemExportToShareableHandle(&fd, as_hip(s.region->handle[s.index]), hipMemHandleTypePosixFileDescriptor, 0));

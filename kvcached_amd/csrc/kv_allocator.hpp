@@ -138,6 +138,10 @@ struct KvRegion {
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
+  // hybrid backend: slots HIP has been told about (placeholder mapping made and removed again), and the placeholder
+  // handles (HIP handles, one per `fanout` slots so that HIP's per-handle bookkeeping stays small)
+  std::vector<uint8_t> registered;
+  std::vector<hipMemGenericAllocationHandle_t> shell;
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
                                        // 3 = released by the caller, physical unmap still queued (async unmap)
   size_t num_slots() const { return size / page_size; }
@@ -187,6 +191,8 @@ private:
   std::unique_ptr<KvRegion> make_region(const std::string &name, size_t size, size_t page_size);
   void destroy_region(KvRegion &r);
   void backfill_all(KvRegion &r);
+  void register_slot(KvRegion &r, size_t slot);   // hybrid backend: make HIP aware of the slot's VA (once per slot)
+  void unregister_slots(KvRegion &r);             // ... and take that back before the VA range is freed
   void map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported);
   void unmap_slots(const std::vector<Slot> &slots);
   // the two halves of unmap_slots: driver unmaps under mu_ (handles collected), then invalidate + give handles back

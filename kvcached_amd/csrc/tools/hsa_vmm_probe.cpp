@@ -197,6 +197,62 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 32; k++) HK(hsa_amd_vmem_unmap(va + (size_t)(k + 1) * PAGE, PAGE));
     break;
   }
+  case 8: { // "registered with HIP once, backed through ROCr": does HIP keep serving copies for a VA whose mapping
+            // it created, after that mapping was replaced behind its back?
+    HK(hsa_amd_vmem_unmap(va, PAGE)); // the op prologue mapped h[0] through ROCr: start from an empty slot
+    void *hva = nullptr;
+    CK(hipMemAddressReserve(&hva, 4 * PAGE, PAGE, nullptr, 0));
+    char *q = (char *)hva;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    hipMemGenericAllocationHandle_t shell;
+    CK(hipMemCreate(&shell, PAGE, &prop, 0));
+    for (int k = 0; k < 4; k++) CK(hipMemMap(q + (size_t)k * PAGE, PAGE, 0, shell, 0)); // HIP now knows these 4 slots
+    for (int k = 0; k < 4; k++) HK(hsa_amd_vmem_unmap(q + (size_t)k * PAGE, PAGE));      // ... and we take them away
+    printf("registered 4 slots with HIP, unmapped them through ROCr\n");
+    for (int round = 0; round < 3; round++) {
+      for (int k = 0; k < 4; k++) {
+        HK(hsa_amd_vmem_map(q + (size_t)k * PAGE, PAGE, 0, h[(round * 4 + k) % n], 0));
+        HK(hsa_amd_vmem_set_access(q + (size_t)k * PAGE, PAGE, &acc, 1));
+      }
+      const unsigned stamp = 0x7700u + round;
+      fill32<<<512, 256, 0, s>>>((unsigned *)q, 4 * PAGE / 4, stamp);
+      CK(hipStreamSynchronize(s));
+      std::vector<unsigned> back(4 * PAGE / 4, 0);
+      double ta = now_us();
+      st = hipMemcpy(back.data(), q, 4 * PAGE, hipMemcpyDeviceToHost);
+      double tb = now_us();
+      size_t wrong = 0;
+      for (unsigned w : back) wrong += w != stamp;
+      printf("round %d: hipMemcpy D2H of 8 MiB: %s, %.1f MB/s, %zu words wrong\n", round, hipGetErrorString(st),
+             8.0 * 1.048576 / ((tb - ta) * 1e-6), wrong);
+      for (auto &w : back) w = 0x9900u + round;
+      st = hipMemcpyAsync(q, back.data(), 4 * PAGE, hipMemcpyHostToDevice, s);
+      CK(hipStreamSynchronize(s));
+      CK(hipMemsetAsync(cnt, 0, 8, s));
+      count_ne<<<512, 256, 0, s>>>((const unsigned *)q, 4 * PAGE / 4, 0x9900u + round, cnt);
+      unsigned long long bad = ~0ull;
+      CK(hipMemcpyAsync(&bad, cnt, 8, hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      printf("         hipMemcpyAsync H2D: %s, kernel sees %llu wrong words\n", hipGetErrorString(st), bad);
+      st = hipMemcpy(dbuf, q + PAGE, 4096, hipMemcpyDeviceToDevice);
+      printf("         D2D: %s\n", hipGetErrorString(st));
+      double tu = now_us();
+      for (int k = 0; k < 4; k++) HK(hsa_amd_vmem_unmap(q + (size_t)k * PAGE, PAGE));
+      printf("         ROCr unmap %.2f us/slot\n", (now_us() - tu) / 4);
+    }
+    // teardown the way HIP expects it: something must be mapped where HIP believes its mapping is
+    for (int k = 0; k < 4; k++) HK(hsa_amd_vmem_map(q + (size_t)k * PAGE, PAGE, 0, h[k], 0));
+    for (int k = 0; k < 4; k++) {
+      st = hipMemUnmap(q + (size_t)k * PAGE, PAGE);
+      if (st != hipSuccess) printf("teardown hipMemUnmap slot %d: %s\n", k, hipGetErrorString(st));
+    }
+    st = hipMemRelease(shell);
+    printf("teardown: release %s, address free %s\n", hipGetErrorString(st), hipGetErrorString(hipMemAddressFree(hva, 4 * PAGE)));
+    HK(hsa_amd_vmem_map(va, PAGE, 0, h[0], 0)); // restore what the epilogue expects
+    break;
+  }
   default: printf("no op\n");
   }
   fflush(stdout);
