@@ -367,6 +367,7 @@ void GpuContext::sync(hipStream_t s) {
 // mapped through ROCr, written with hipMemset and read back with hipMemcpy. Any surprise -> the plain HIP backend.
 namespace {
 bool hybrid_self_test(int dev) {
+  if (env_bool("KVCACHED_TEST_FAIL_HYBRID_SELFTEST", false)) return false; // tests: exercise the fallback
   const size_t ps = kBasePage;
   void *va = nullptr;
   hipMemGenericAllocationHandle_t shell = nullptr;
