@@ -2,6 +2,8 @@
 // immediately after hipMemUnmap + hipMemMap + hipMemSetAccess? Pure HIP, no torch.
 // Build: hipcc --offload-arch=gfx950 -O2 -std=c++17 remap_diag.cpp -o remap_diag
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +110,34 @@ static void flush_trigger(int mode) {
     if (!m) { CK(hipMallocManaged((void **)&m, 2u << 20, hipMemAttachGlobal)); m[0] = 1; t0 = std::chrono::steady_clock::now(); }
     CK(hipMemPrefetchAsync(m, 2u << 20, (flip++ & 1) ? hipCpuDeviceId : 0, 0));
     CK(hipStreamSynchronize(0));
+    break;
+  }
+  case 21:   // ROCr: re-grant the GPU access to a small, persistent host-pool buffer (a KFD map ioctl every time?)
+  case 22: { // ... or to a small device-pool buffer
+    static hsa_agent_t gpu, cpu;
+    static void *buf = nullptr;
+    if (!buf) {
+      hsa_init();
+      struct F { hsa_agent_t g, c; bool hg = false, hc = false; } f;
+      hsa_iterate_agents([](hsa_agent_t a, void *q) -> hsa_status_t {
+        auto *f = (F *)q; hsa_device_type_t t; hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t);
+        if (t == HSA_DEVICE_TYPE_GPU && !f->hg) { f->g = a; f->hg = true; }
+        if (t == HSA_DEVICE_TYPE_CPU && !f->hc) { f->c = a; f->hc = true; }
+        return HSA_STATUS_SUCCESS; }, &f);
+      gpu = f.g; cpu = f.c;
+      struct P { hsa_amd_memory_pool_t p; bool found = false; bool want_fine; } pp;
+      pp.want_fine = mode == 21;
+      hsa_amd_agent_iterate_memory_pools(mode == 21 ? cpu : gpu, [](hsa_amd_memory_pool_t p, void *q) -> hsa_status_t {
+        auto *o = (P *)q; hsa_amd_segment_t seg; bool alloc = false; uint32_t fl = 0;
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+        hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &fl);
+        if (seg == HSA_AMD_SEGMENT_GLOBAL && alloc && !o->found) { o->p = p; o->found = true; }
+        return HSA_STATUS_SUCCESS; }, &pp);
+      if (hsa_amd_memory_pool_allocate(pp.p, 4096, 0, &buf) != HSA_STATUS_SUCCESS) { printf("pool allocate failed\n"); exit(1); }
+      t0 = std::chrono::steady_clock::now();
+    }
+    if (hsa_amd_agents_allow_access(1, &gpu, nullptr, buf) != HSA_STATUS_SUCCESS) printf("allow_access failed\n");
     break;
   }
   case 19: CK(hipMalloc(&p, 1u << 20)); CK(hipFree(p)); break;          // 1 MiB
