@@ -1,14 +1,16 @@
-// hip_vmm.hpp — the only file that talks to ROCm's virtual-memory-management API.
+// hip_vmm.hpp — the only file that talks to ROCm's virtual-memory-management APIs.
 //
-// Written directly against hipMemAddressReserve / hipMemCreate / hipMemMap /
-// hipMemSetAccess / hipMemUnmap / hipMemRelease (HIP only; the reference's
-// csrc/inc/gpu_vmm.hpp is a CUDA/HIP dual shim — this is not). Measured costs on MI355X /
-// ROCm 7.2 that shaped the design (gpurun_out/vmm_probe_r01.log):
-//   create 3.4 us | map 6.5 us (3.7 us for a recycled handle) | set_access 4.0 us
-//   (3.4 us/page when one call spans many mappings) | unmap 15 us | release 2.7 us;
-//   the cost is per MAPPING, not per byte, and driver calls do not scale across threads.
-// Hence: recycle handles (PhysPool), never touch a slot twice (optional zero backfill),
-// range the set_access, and overlap the fill kernel with the remaining driver calls.
+// Two APIs reach the same driver: HIP's (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess /
+// hipMemUnmap / hipMemRelease) and ROCr's (hsa_amd_vmem_*), which HIP sits on. Every verb below exists in both
+// forms; KVCACHED_VMM_BACKEND picks the combination (hybrid, hip, hsa - see the comment above vmm_backend()).
+// No CUDA branch anywhere (the reference's csrc/inc/gpu_vmm.hpp is a CUDA/HIP dual shim - this is not).
+// Measured costs on MI355X / ROCm 7.2 that shaped the design (profiles/r01_*), per 2 MiB mapping:
+//   HIP : create 3.4 us | map 3.1 us | set_access 3.3 us | unmap 12-15 us (10 of them a GPU-marker spin) | release 3-50 us
+//   ROCr: create 3.3 us | map 2.3 us | set_access 3.0 us | unmap 2.8 us
+//   creation is O(live handles) in ROCr's user space with either; the cost is per MAPPING, not per byte; no call
+//   scales across threads of one process; no partial unmap and no working map offset.
+// Hence: recycle handles (PhysPool), never touch a slot twice, one batch per call with the fill kernel overlapped,
+// and unmap through ROCr on VA that HIP has been introduced to once.
 #pragma once
 
 #include <hip/hip_runtime.h>
