@@ -24,7 +24,8 @@ static hsa_amd_memory_pool_t g_pool;
 static bool g_hg = false, g_hp = false;
 int main(int argc, char **argv) {
   const int total = argc > 1 ? atoi(argv[1]) : 32768;
-  const bool map_too = argc > 2; // also map + grant every handle (live mappings instead of bare handles)
+  const bool map_too = argc > 2 && argv[2][0] == 'm'; // also map + grant every handle (live mappings instead of bare handles)
+  const hsa_amd_memory_type_t mtype = (argc > 3 && argv[3][0] == 'n') ? MEMORY_TYPE_NONE : MEMORY_TYPE_PINNED;
   const size_t PAGE = 2u << 20;
   if (hipSetDevice(0) != hipSuccess || hipFree(nullptr) != hipSuccess) return 1;
   hsa_init();
@@ -48,7 +49,7 @@ int main(int argc, char **argv) {
     double tc = 0, tm = 0;
     for (int i = base; i < base + 4096 && i < total; i++) {
       double a = now_us();
-      if (hsa_amd_vmem_handle_create(g_pool, PAGE, MEMORY_TYPE_PINNED, 0, &h[i]) != HSA_STATUS_SUCCESS) { printf("create failed at %d\n", i); return 3; }
+      if (hsa_amd_vmem_handle_create(g_pool, PAGE, mtype, 0, &h[i]) != HSA_STATUS_SUCCESS) { printf("create failed at %d\n", i); return 3; }
       double b = now_us();
       tc += b - a;
       if (map_too) {
