@@ -155,10 +155,14 @@ void GpuContext::housekeeping() {
     for (auto *p : ps) p->drain(0);
     return;
   }
-  for (auto *p : ps) p->trim_to_cap(1024); // what release_batch left above the cap (deferred eviction)
+  // Releasing memory the GPU has touched costs 50-60 us per handle (the KFD free ioctl) and driver calls of one
+  // process do not overlap: 256 handles per 100 ms tick keeps this thread's share of the driver under ~15 % while
+  // still returning 5 GiB/s.
+  constexpr size_t kPerTick = 256;
+  for (auto *p : ps) p->trim_to_cap(kPerTick); // what release_batch left above the cap (deferred eviction)
   const int64_t idle_ms = options().pool_idle_ms.load();
   if (idle_ms > 0)
-    for (auto *p : ps) p->decay(now_ns(), idle_ms * 1000000ll, 1024);
+    for (auto *p : ps) p->decay(now_ns(), idle_ms * 1000000ll, kPerTick);
 }
 
 void GpuContext::begin_timed(hipStream_t s, int kind) {
