@@ -254,6 +254,40 @@ def test_default_backend_is_hybrid_and_falls_back_when_its_self_test_fails(vmm):
     assert ops.unmap_from_kv_tensors([PAGE])
 
 
+def test_larger_page_size_8MiB(vmm):
+    """KVCACHED_PAGE_SIZE_MB=8 (a multiple of 2 MiB, utils.py:95-124): slots, placeholders, zero fill and the handle
+    ledger all follow the page size; fewer, larger mappings are what the driver charges least for."""
+    ops, capi = vmm["ops"], vmm["capi"]
+    P8 = 8 * MiB
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "false"
+    try:
+        ops.init_kvcached(DEV, P8, False)
+    finally:
+        os.environ.pop("KVCACHED_ZERO_BACKFILL", None)
+    ts = ops.create_kv_tensors(64 * P8 * 2, 2, DEV, 2, 2, 0, False)
+    epp = P8 // 2
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([5 * P8, 2 * P8, 9 * P8])
+    st = capi.get_stats()
+    assert st["pages_mapped"] == 3 * 2 * 2 and st["fill_bytes"] == 12 * P8
+    half = ts[0].numel() // 2
+    for t in ts:
+        for base in (0, half):
+            for p in (5, 2, 9):
+                page = t[base + p * epp: base + (p + 1) * epp]
+                assert int(torch.count_nonzero(page)) == 0
+                page.fill_(p)
+    torch.cuda.synchronize()
+    assert ts[1][half + 9 * epp: half + 9 * epp + 4].cpu().tolist() == [9] * 4
+    with pytest.raises(RuntimeError):
+        ops.map_to_kv_tensors([P8 + MiB])                       # offsets must be page-size multiples
+    assert ops.unmap_from_kv_tensors([5 * P8, 2 * P8, 9 * P8])
+    assert ops.map_to_kv_tensors([2 * P8])                        # recycled 8 MiB handles read zero again
+    assert int(torch.count_nonzero(ts[0][2 * epp:3 * epp])) == 0
+    assert ops.unmap_from_kv_tensors([2 * P8])
+    assert capi.get_stats()["pages_unmapped"] == 16
+
+
 def test_contiguous_layout_compound_pages(vmm):
     """One region for all layers; an offset backs page x layers x kv bytes in ONE mapping."""
     layers = 4
