@@ -84,7 +84,7 @@ class Pool:
             os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
         else:
             os.environ.pop("KVCACHED_PHYS_POOL_MB", None)
-        self.size = window_batches * BATCH_PAGES * page
+        self.size = window_batches * BATCH_PAGES * PAGE       # 64 GiB of VA whatever the slot size
         t0 = time.perf_counter()
         if compound_layers:
             # contiguous layout: one region, slot = compound page (2 MiB x layers x K/V), e.g. 128 MiB for Llama-3-8B
@@ -116,14 +116,14 @@ def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
 
 
 def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0,
-            burst=False, prefault=True, backend="hybrid"):
+            burst=False, prefault=True, backend="hybrid", page=PAGE):
     """cycle (default): every step maps+zeroes one batch and unmaps it again. burst=True: `steps` batches are
     backed one after the other and only unmapped after the timed region.
     prefault: as in the bench_vmm protocol (warm-up sweeps over the whole window before the timed sweeps), every batch
     of the window is mapped and unmapped once during set-up - the state of an engine that has been running for a
     second. prefault=False skips the sweep (the timed steps then touch VA that was never mapped)."""
     window = max(32, steps + warmup) if burst else 32  # 64 GiB of VA
-    pool = Pool(capi, device, window, mode, pool_mb, compound_layers=compound_layers, backend=backend)
+    pool = Pool(capi, device, window, mode, pool_mb, page=page, compound_layers=compound_layers, backend=backend)
     slot = pool.slot
     try:
         if fanout is not None:
@@ -453,12 +453,14 @@ def main():
                         ("growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),   # growth = fresh VA, fresh handles
                         ("no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
                         ("compat_zero_backfill_sharded", "compat", None, 0, False, True),
+                        ("page_size_8MiB_instead_of_2MiB", "lazy", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
                         nsteps = 24 if (burst or name.startswith("fresh_va") or name == "hip_backend_same_cycle") else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
                                      backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
-                                     else ("hip" if name.startswith("hip_") else args.backend))
+                                     else ("hip" if name.startswith("hip_") else args.backend),
+                                     page=8 * MiB if name.startswith("page_size_8MiB") else PAGE)
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
                                           for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",
