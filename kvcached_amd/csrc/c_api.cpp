@@ -127,6 +127,7 @@ int kvc_set_option(int opt, int64_t value) {
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
   case 107: options().pool_idle_ms = value < 0 ? 0 : value; break;
+  case 109: options().async_shootdown = value; break;
   case 104: fail_after_creates() = value; break;       // fault injection: the (value+1)-th hipMemCreate fails
   case 100: options().fill_variant = value; break;    // tuning only
   case 101: options().compact_variant = value; break; // tuning only
@@ -147,6 +148,7 @@ int64_t kvc_get_option(int opt) {
   case 103: return options().zero_alias_fanout;
   case 105: return options().fill_chunk_slots;
   case 107: return options().pool_idle_ms;
+  case 109: return options().async_shootdown;
   case 108: return vmm_backend().load(); // effective VMM backend: 0 hip, 1 hsa, 2 hybrid (read-only)
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;

@@ -151,6 +151,11 @@ void GpuContext::housekeeping() {
   }
   if (ps.empty()) return;
   (void)hipSetDevice(dev_);
+  try {
+    flush_deferred_shootdown(); // the invalidation unmap batches left to this thread (KVCACHED_ASYNC_SHOOTDOWN)
+  } catch (const std::exception &e) {
+    KVC_LOG(LOG_ERROR, "housekeeping: TLB invalidation failed: %s", e.what());
+  }
   if (ps[0]->under_pressure()) {
     for (auto *p : ps) p->drain(0);
     return;
@@ -453,6 +458,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().defer_unmap_shootdown = env_bool("KVCACHED_DEFER_UNMAP_SHOOTDOWN", false) ? 1 : 0;
   options().pool_idle_ms = std::max<int64_t>(0, env_i64("KVCACHED_POOL_IDLE_MS", 1000));
   options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
+  options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
     const std::string b = be ? be : "hybrid";
@@ -1246,7 +1252,12 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   //     for the page-table updates the unmaps queued, so it only moves from free() into the next alloc()
   //     (per page: unmap 354 -> 21 us, next map 205 -> 379 us; batches unchanged).
   //   * memory leaving this process (imported pages, pool evictions): invalidate first.
-  if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !options().defer_unmap_shootdown.load())
+  //   * who pays: with an allocator watcher thread around (an engine, not a bare C-ABI caller) the owed invalidation
+  //     is left to its next 100 ms tick (GpuContext::housekeeping) - the 0.3-0.4 ms KFD round trip leaves the
+  //     caller's free() and, unless an alloc follows within that tick, reaches nobody's critical path
+  //     (KVCACHED_ASYNC_SHOOTDOWN, on by default; one page id: free() 0.6 -> 0.2 ms).
+  const bool defer = options().defer_unmap_shootdown.load() || (options().async_shootdown.load() && ctx->has_housekeeper());
+  if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer)
     ctx->tlb_shootdown();
   else
     ctx->defer_tlb_shootdown();

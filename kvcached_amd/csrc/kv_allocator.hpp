@@ -31,6 +31,7 @@ struct Options {
   std::atomic<int64_t> tlb_shootdown{1};
   std::atomic<int64_t> pool_idle_ms{1000};       // idle handles older than this are released (0 = keep until pressure)
   std::atomic<int64_t> async_unmap{0};           // unmap_from_kv_tensors only queues; a reclaimer thread does the driver calls
+  std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
@@ -74,6 +75,7 @@ public:
   // a thread that calls housekeeping() periodically exists / is gone (PageAllocator's watcher): while one does,
   // pools hand over-cap handles to it instead of releasing them on the caller's free() path
   void add_housekeeper(int delta);
+  bool has_housekeeper() const { return housekeepers_.load() > 0; }
 
   // kernel launches on `s` (NULL = own stream), timed with events when profiling is on
   void zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s);
