@@ -114,9 +114,11 @@ inline const HsaDevice &hsa_device(int hip_dev) {
   HIP_CHECK(hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_dev));
   (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, hip_dev);
   (void)hipGetLastError();
+  // bus + device identify the GPU on all but exotic hosts; the PCI domain only breaks ties (older HIP runtimes do not
+  // report it, multi-domain hosts need it)
   struct Find {
     int bus, dev, dom;
-    bool found = false;
+    bool found = false, exact = false;
     HsaDevice d;
   } f{bus, dev, dom};
   HSA_CHECK(hsa_iterate_agents(
@@ -132,9 +134,12 @@ inline const HsaDevice &hsa_device(int hip_dev) {
         uint32_t bdf = 0, domain = 0;
         (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
         (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
-        if ((int)((bdf >> 8) & 0xff) == f->bus && (int)((bdf >> 3) & 0x1f) == f->dev && (int)domain == f->dom && !f->found) {
+        if ((int)((bdf >> 8) & 0xff) != f->bus || (int)((bdf >> 3) & 0x1f) != f->dev) return HSA_STATUS_SUCCESS;
+        const bool exact = (int)domain == f->dom;
+        if (!f->found || (exact && !f->exact)) {
           f->d.agent = a;
           f->found = true;
+          f->exact = exact;
         }
         return HSA_STATUS_SUCCESS;
       },
