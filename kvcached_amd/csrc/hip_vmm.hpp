@@ -119,6 +119,7 @@ inline const HsaDevice &hsa_device(int hip_dev) {
   struct Find {
     int bus, dev, dom;
     bool found = false, exact = false;
+    int n_loose = 0, n_exact = 0;
     HsaDevice d;
   } f{bus, dev, dom};
   HSA_CHECK(hsa_iterate_agents(
@@ -136,6 +137,8 @@ inline const HsaDevice &hsa_device(int hip_dev) {
         (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
         if ((int)((bdf >> 8) & 0xff) != f->bus || (int)((bdf >> 3) & 0x1f) != f->dev) return HSA_STATUS_SUCCESS;
         const bool exact = (int)domain == f->dom;
+        ++f->n_loose;
+        if (exact) ++f->n_exact;
         if (!f->found || (exact && !f->exact)) {
           f->d.agent = a;
           f->found = true;
@@ -145,6 +148,9 @@ inline const HsaDevice &hsa_device(int hip_dev) {
       },
       &f));
   if (!f.found) throw GpuError("no ROCr agent matches HIP device " + std::to_string(hip_dev));
+  // several agents behind one PCI address (partitioned GPU): never guess - the caller falls back to the HIP backend
+  if (f.n_exact > 1 || (f.n_exact == 0 && f.n_loose > 1))
+    throw GpuError("HIP device " + std::to_string(hip_dev) + " cannot be matched to ONE ROCr agent by PCI address");
   struct Pool {
     bool found = false;
     hsa_amd_memory_pool_t p{};
