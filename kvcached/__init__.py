@@ -1,7 +1,7 @@
 """`kvcached` — import-compatibility alias of kvcached_amd.
 
 The reference's engine patches, tools and tests import `kvcached.vmm_ops`,
-`kvcached.kv_cache_manager`, `kvcached.tp_ipc_util`, `kvcached.utils`, `kvcached.locks` and
+`kvcached.kv_cache_manager`, `kvcached.tp_ipc_util`, `kvcached.utils`, `kvcached.locks`, `kvcached.mem_info_tracker`, `kvcached.cli.utils` and
 `kvcached.integration.{vllm,sglang}.interfaces`. This package contains no logic: it registers the
 kvcached_amd modules under those names so that the existing imports resolve to the MI355X-native
 implementation unchanged. Out-of-scope reference modules (engine patches, CLI, controller) are not
@@ -20,6 +20,9 @@ _ALIASES = {
     "kvcached.locks": "kvcached_amd.locks",
     "kvcached.tp_ipc_util": "kvcached_amd.tp_ipc_util",
     "kvcached.kv_cache_manager": "kvcached_amd.kv_cache_manager",
+    "kvcached.cli": "kvcached_amd.cli",
+    "kvcached.cli.utils": "kvcached_amd.cli.utils",
+    "kvcached.mem_info_tracker": "kvcached_amd.mem_info_tracker",
     "kvcached.integration": "kvcached_amd.integration",
     "kvcached.integration.vllm": "kvcached_amd.integration.vllm",
     "kvcached.integration.vllm.interfaces": "kvcached_amd.integration.vllm.interfaces",

@@ -11,7 +11,9 @@
 // are published with two relaxed 8-byte atomic stores and total_size is read with one atomic
 // load. This is safe with stock kvctl because the fields have single writers: only the engine
 // writes [1] and [2], only the controller writes [0] after creation, and an aligned 8-byte
-// store cannot tear. The creation write (all three fields) still takes flock(LOCK_EX) like the
+// store cannot tear; a controller's read-modify-write that races with one of our stores and writes a
+// stale used/prealloc back is repaired by the next page event or, at the latest, the next 100 ms
+// watcher tick (revalidate()). The creation write (all three fields) still takes flock(LOCK_EX) like the
 // reference. If the file is deleted or replaced underneath us (kvctl delete), revalidate()
 // notices the inode change and re-creates it, as the reference's open-by-path would.
 #pragma once
@@ -53,6 +55,8 @@ public:
 
   void update_memory_usage(int64_t used, int64_t prealloc) {
     std::lock_guard<std::mutex> g(mu_);
+    pub_used_ = used;
+    pub_prealloc_ = prealloc;
     if (!arr_) return;
     __atomic_store_n(&arr_[1], used, __ATOMIC_RELAXED);
     __atomic_store_n(&arr_[2], prealloc, __ATOMIC_RELAXED);
@@ -72,14 +76,21 @@ public:
   void revalidate() {
     std::lock_guard<std::mutex> g(mu_);
     struct stat now {};
-    if (::stat(path_.c_str(), &now) == 0 && now.st_ino == ino_ && now.st_dev == dev_) return;
-    int64_t used = arr_ ? arr_[1] : 0, pre = arr_ ? arr_[2] : 0;
+    if (::stat(path_.c_str(), &now) == 0 && now.st_ino == ino_ && now.st_dev == dev_) {
+      // kvctl's limit update is a read-modify-write of all three fields under flock: racing with one of our
+      // lock-free stores it can write a stale used/prealloc back. We are their only writer, so re-assert.
+      if (arr_ && __atomic_load_n(&arr_[1], __ATOMIC_RELAXED) != pub_used_)
+        __atomic_store_n(&arr_[1], pub_used_, __ATOMIC_RELAXED);
+      if (arr_ && __atomic_load_n(&arr_[2], __ATOMIC_RELAXED) != pub_prealloc_)
+        __atomic_store_n(&arr_[2], pub_prealloc_, __ATOMIC_RELAXED);
+      return;
+    }
     close_segment();
     open_segment(/*init=*/false);
     if (arr_) {
       if (arr_[0] == 0) arr_[0] = total_mem_size_;
-      arr_[1] = used;
-      arr_[2] = pre;
+      arr_[1] = pub_used_;
+      arr_[2] = pub_prealloc_;
     }
   }
 
@@ -126,6 +137,7 @@ private:
 
   std::string ipc_name_, path_;
   int64_t total_mem_size_;
+  int64_t pub_used_ = 0, pub_prealloc_ = 0; // what this engine last published (guarded by mu_)
   std::mutex mu_;
   int fd_ = -1;
   int64_t *arr_ = nullptr;
