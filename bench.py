@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", choices=["hip", "hybrid", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "hybrid"),
+    ap.add_argument("--backend", choices=["hip", "hybrid", "drm", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "hybrid"),
                     help="VMM backend of the main measurement (DESIGN.md §4.6)")
     return ap.parse_args()
 

@@ -88,12 +88,15 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              driver, whichever comes first; 0 (default) = invalidate inside every unmap call
  *                              (the cost only moves from free() to the next alloc()).
  *                              Compat mode (ZERO_BACKFILL) and imported pages always invalidate at once.
- *   (environment only) KVCACHED_VMM_BACKEND = hybrid (default) | hip | hsa: which API backs the slots. hybrid
+ *   (environment only) KVCACHED_VMM_BACKEND = hybrid | drm | hip | hsa: which API backs the slots. hybrid
  *                              registers each slot with HIP once and then maps/unmaps it through ROCr's
  *                              hsa_amd_vmem_* (hipMemUnmap spins ~10 us on a GPU marker per mapping; ROCr's unmap
  *                              takes 3 us) - every hipMemcpy flavour keeps working; checked by a self test at
  *                              kvc_init, which falls back to hip. kvc_get_option(108) reports the backend in
- *                              effect (0 hip, 1 hsa, 2 hybrid). DESIGN.md §4.6.
+ *                              effect (0 hip, 1 hsa, 2 hybrid, 3 drm). drm = hybrid, and this process's own
+ *                              pages are mapped/unmapped with one DRM_AMDGPU_GEM_VA ioctl each through
+ *                              libdrm_amdgpu on buffer objects imported once per handle (2.2 + 2.1 us per page
+ *                              instead of 5.3 + 2.8); self-tested at kvc_init, falls back to hybrid. DESIGN.md §4.6/§4.7.
  *   KVC_OPT_ASYNC_UNMAP    1 = kvc_unmap_from_kv_tensors only marks the slots and queues them; a reclaimer thread
  *                              of the library carries out hipMemUnmap + invalidation + handle recycling in small
  *                              chunks, yielding to map calls. A slot that is mapped again before its turn is kept

@@ -17,8 +17,17 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <dirent.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <limits.h>
+#include <strings.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
+#include <cstring>
 #include <iterator>
 #include <functional>
 #include <map>
@@ -61,7 +70,7 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 // works on the KV tensors), KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only.
 using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer) or hsa_amd_vmem_alloc_handle_t::handle
 
-enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2 };
+enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2, kVmmDrm = 3 };
 // kVmmHybrid: VA reserved through HIP and every slot registered with HIP once (hipMemMap of a placeholder handle,
 // taken away again through ROCr at once); from then on the slot is backed and unbacked with hsa_amd_vmem_* only.
 // HIP keeps resolving the pointer (its copies use the VA, the hardware walks the page tables ROCr wrote): every
@@ -71,6 +80,13 @@ inline std::atomic<int> &vmm_backend() { // set by KvAllocator::init from KVCACH
   return v;
 }
 inline bool vmm_uses_rocr() { return vmm_backend().load() != kVmmHip; }
+// kVmmDrm: hybrid, plus this process's own pages are mapped and unmapped with ONE ioctl each (DrmVm below) instead of
+// ROCr's export + import + mmap + GEM_VA (+ GEM_CLOSE) per call. Everything else (aliases, imported handles,
+// registration with HIP, export) is the hybrid backend's.
+inline bool vmm_hip_registered() {
+  const int b = vmm_backend().load();
+  return b == kVmmHybrid || b == kVmmDrm;
+}
 
 inline void hsa_check(hsa_status_t st, const char *tok, const char *file, int line) {
   if (st == HSA_STATUS_SUCCESS) return;
@@ -177,6 +193,168 @@ inline const HsaDevice &hsa_device(int hip_dev) {
   return cache.emplace(hip_dev, f.d).first->second;
 }
 
+
+// ---- DrmVm: the process's GPU address space, driven through libdrm_amdgpu directly.
+// What ROCr does per hsa_amd_vmem_map / set_access / unmap (tools/ioctl_timer.c, profiles/r01_unmap_trace_ioctls.log):
+// export the handle from KFD as a dmabuf, import it into DRM, query it, mmap; export and import AGAIN, then the one
+// ioctl that edits the page tables (DRM_AMDGPU_GEM_VA, 2.8 us); on unmap GEM_VA (2.4 us) + GEM_CLOSE. 8.1 us per
+// map+unmap cycle, 5.2 of them GEM_VA. Keeping the imported buffer object for the lifetime of the handle leaves
+// exactly those two ioctls (tools/drm_vmm_probe.cpp: map 2.2 us, unmap 2.1 us per 2 MiB page).
+// Why this is the right address space: ROCr itself edits it through libdrm_amdgpu's amdgpu_bo_va_op on the
+// amdgpu_device its thunk initialised for the render node whose VM KFD acquired; libdrm keeps ONE amdgpu_device per
+// node and process, so amdgpu_device_initialize() on our own fd of that node returns the same device. That is a
+// property of the library, not a contract: open() proves it before any memory is touched (a map over a VA that
+// ROCr has mapped must be refused - mappings of one VM may not overlap) and the backend falls back to hybrid otherwise.
+// libdrm_amdgpu is loaded with dlopen (ROCr links it, so the very same instance is already in the process); the
+// five prototypes below are its stable public ABI (amdgpu.h), restated so that no -dev package is needed to build.
+class DrmVm {
+public:
+  static DrmVm &instance() {
+    static DrmVm v;
+    return v;
+  }
+  bool ready() const { return dev_ != nullptr; }
+  int hip_dev() const { return hip_dev_; }
+
+  // Opens the render node of HIP device `hip_dev` (matched by PCI address). Returns false with a reason.
+  bool open(int hip_dev, std::string *why) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (dev_ && hip_dev_ == hip_dev) return true;
+    if (dev_) close_locked();
+    if (!load_api(why)) return false;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, hip_dev) != hipSuccess) {
+      (void)hipGetLastError();
+      *why = "hipDeviceGetPCIBusId failed";
+      return false;
+    }
+    const std::string node = render_node_for(bdf);
+    if (node.empty()) {
+      *why = std::string("no DRM render node for ") + bdf;
+      return false;
+    }
+    fd_ = ::open(node.c_str(), O_RDWR | O_CLOEXEC);
+    if (fd_ < 0) {
+      *why = "cannot open " + node + ": " + strerror(errno);
+      return false;
+    }
+    uint32_t major = 0, minor = 0;
+    const int r = api_.device_initialize(fd_, &major, &minor, &dev_);
+    if (r != 0 || !dev_) {
+      *why = "amdgpu_device_initialize(" + node + ") failed: " + strerror(r < 0 ? -r : r);
+      ::close(fd_);
+      fd_ = -1;
+      dev_ = nullptr;
+      return false;
+    }
+    hip_dev_ = hip_dev;
+    return true;
+  }
+  void close() {
+    std::lock_guard<std::mutex> g(mu_);
+    close_locked();
+  }
+
+  // Import the ROCr handle's memory into DRM once; from then on find(h) answers. False: the handle stays ROCr-only.
+  bool adopt(phys_handle_t h) {
+    int dmabuf = -1;
+    if (hsa_amd_vmem_export_shareable_handle(&dmabuf, hsa_amd_vmem_alloc_handle_t{h}, 0) != HSA_STATUS_SUCCESS) return false;
+    ImportResult res{};
+    std::lock_guard<std::mutex> g(mu_);
+    const int r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, (uint32_t)dmabuf, &res) : -ENODEV;
+    ::close(dmabuf);
+    if (r != 0 || !res.bo) return false;
+    bo_[h] = res.bo;
+    return true;
+  }
+  void *find(phys_handle_t h) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = bo_.find(h);
+    return it == bo_.end() ? nullptr : it->second;
+  }
+  // Before the ROCr handle is released: drop DRM's reference.
+  void forget(phys_handle_t h) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = bo_.find(h);
+    if (it == bo_.end()) return;
+    (void)api_.bo_free(it->second);
+    bo_.erase(it);
+  }
+  size_t adopted() {
+    std::lock_guard<std::mutex> g(mu_);
+    return bo_.size();
+  }
+  // 0 or a negative errno. The kernel serialises page-table edits per VM; no lock of ours is held across the ioctl.
+  int map(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpMap); }
+  int unmap(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpUnmap); }
+
+private:
+  struct ImportResult { // struct amdgpu_bo_import_result
+    void *bo;
+    uint64_t alloc_size;
+  };
+  static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
+  static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2; // AMDGPU_VA_OP_MAP / _UNMAP
+  struct Api {
+    int (*device_initialize)(int, uint32_t *, uint32_t *, void **) = nullptr;
+    int (*device_deinitialize)(void *) = nullptr;
+    int (*bo_import)(void *, int, uint32_t, ImportResult *) = nullptr;
+    int (*bo_free)(void *) = nullptr;
+    int (*bo_va_op)(void *, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t) = nullptr;
+  };
+
+  bool load_api(std::string *why) {
+    if (api_.bo_va_op) return true;
+    void *lib = dlopen("libdrm_amdgpu.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+      *why = std::string("dlopen(libdrm_amdgpu.so.1): ") + dlerror();
+      return false;
+    }
+    Api a;
+    a.device_initialize = reinterpret_cast<decltype(a.device_initialize)>(dlsym(lib, "amdgpu_device_initialize"));
+    a.device_deinitialize = reinterpret_cast<decltype(a.device_deinitialize)>(dlsym(lib, "amdgpu_device_deinitialize"));
+    a.bo_import = reinterpret_cast<decltype(a.bo_import)>(dlsym(lib, "amdgpu_bo_import"));
+    a.bo_free = reinterpret_cast<decltype(a.bo_free)>(dlsym(lib, "amdgpu_bo_free"));
+    a.bo_va_op = reinterpret_cast<decltype(a.bo_va_op)>(dlsym(lib, "amdgpu_bo_va_op"));
+    if (!a.device_initialize || !a.device_deinitialize || !a.bo_import || !a.bo_free || !a.bo_va_op) {
+      *why = "libdrm_amdgpu.so.1 lacks an expected symbol";
+      return false;
+    }
+    api_ = a;
+    return true;
+  }
+  static std::string render_node_for(const char *bdf) {
+    std::string found;
+    DIR *d = opendir("/sys/class/drm");
+    if (!d) return found;
+    while (dirent *e = readdir(d)) {
+      if (strncmp(e->d_name, "renderD", 7) != 0) continue;
+      char link[PATH_MAX], real[PATH_MAX];
+      snprintf(link, sizeof link, "/sys/class/drm/%s/device", e->d_name);
+      if (!realpath(link, real)) continue;
+      const char *leaf = strrchr(real, '/');
+      if (leaf && strcasecmp(leaf + 1, bdf) == 0) found = std::string("/dev/dri/") + e->d_name;
+    }
+    closedir(d);
+    return found;
+  }
+  void close_locked() {
+    for (auto &kv : bo_) (void)api_.bo_free(kv.second);
+    bo_.clear();
+    if (dev_) (void)api_.device_deinitialize(dev_);
+    dev_ = nullptr;
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
+    hip_dev_ = -1;
+  }
+
+  std::mutex mu_;
+  Api api_;
+  void *dev_ = nullptr; // amdgpu_device_handle
+  int fd_ = -1, hip_dev_ = -1;
+  std::unordered_map<phys_handle_t, void *> bo_; // ROCr handle -> amdgpu_bo_handle
+};
+
 inline hipMemAllocationProp make_alloc_prop(int dev, bool exportable) {
   hipMemAllocationProp prop{};
   prop.type = hipMemAllocationTypePinned;
@@ -208,10 +386,16 @@ inline bool vmm_try_address_free(void *va, size_t size) {
   if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_address_free(va, size) == HSA_STATUS_SUCCESS;
   return hipMemAddressFree(va, size) == hipSuccess;
 }
-inline phys_handle_t vmm_create(int dev, size_t size, bool exportable) {
+// `direct`: with the drm backend, also import the handle into DRM so that vmm_map/vmm_unmap take the one-ioctl path
+// (false for handles that are mapped many times over - the zero aliases - which stay with ROCr).
+inline phys_handle_t vmm_create(int dev, size_t size, bool exportable, bool direct = true) {
   if (vmm_uses_rocr()) {
     hsa_amd_vmem_alloc_handle_t h{};
     HSA_CHECK(hsa_amd_vmem_handle_create(hsa_device(dev).pool, size, MEMORY_TYPE_PINNED, 0, &h));
+    if (direct && vmm_backend() == kVmmDrm && DrmVm::instance().hip_dev() == dev && !DrmVm::instance().adopt(h.handle)) {
+      (void)hsa_amd_vmem_handle_release(h);
+      throw GpuError("importing a physical handle into DRM failed (KVCACHED_VMM_BACKEND=drm)");
+    }
     return h.handle;
   }
   hipMemGenericAllocationHandle_t h{};
@@ -220,16 +404,26 @@ inline phys_handle_t vmm_create(int dev, size_t size, bool exportable) {
   return reinterpret_cast<phys_handle_t>(h);
 }
 inline bool vmm_try_release(phys_handle_t h) {
+  if (vmm_backend() == kVmmDrm) DrmVm::instance().forget(h);
   if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }
-inline void vmm_map(void *va, size_t size, phys_handle_t h) {
+inline void *vmm_direct_bo(phys_handle_t h) { return vmm_backend() == kVmmDrm ? DrmVm::instance().find(h) : nullptr; }
+// Returns whether the mapping still needs vmm_set_access (a DRM mapping is made readable+writable in the same ioctl).
+inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
+  if (void *bo = vmm_direct_bo(h)) {
+    const int r = DrmVm::instance().map(bo, va, size);
+    if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
+    return false;
+  }
   if (vmm_uses_rocr())
     HSA_CHECK(hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0));
   else
     HIP_CHECK(hipMemMap(va, size, 0, as_hip(h), 0));
+  return true;
 }
 inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
+  if (void *bo = vmm_direct_bo(h)) return DrmVm::instance().map(bo, va, size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
   return hipMemMap(va, size, 0, as_hip(h), 0) == hipSuccess;
 }
@@ -256,13 +450,21 @@ inline bool vmm_try_set_access(void *va, size_t size, int dev) {
   const auto acc = make_rw_access(dev);
   return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
 }
-inline void vmm_unmap(void *va, size_t size) {
+// `h`: the handle mapped at `va`, when the caller knows it (needed to undo a direct DRM mapping; 0 = an alias or
+// a range, which are always ROCr's / HIP's).
+inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
+  if (void *bo = h ? vmm_direct_bo(h) : nullptr) {
+    const int r = DrmVm::instance().unmap(bo, va, size);
+    if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA unmap failed: ") + strerror(r < 0 ? -r : r));
+    return;
+  }
   if (vmm_uses_rocr())
     HSA_CHECK(hsa_amd_vmem_unmap(va, size));
   else
     HIP_CHECK(hipMemUnmap(va, size));
 }
-inline bool vmm_try_unmap(void *va, size_t size) {
+inline bool vmm_try_unmap(void *va, size_t size, phys_handle_t h = 0) {
+  if (void *bo = h ? vmm_direct_bo(h) : nullptr) return DrmVm::instance().unmap(bo, va, size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
   const bool ok = hipMemUnmap(va, size) == hipSuccess;
   if (!ok) (void)hipGetLastError();

@@ -428,6 +428,108 @@ bool hybrid_self_test(int dev) {
   (void)hipGetLastError();
   return ok;
 }
+
+// The drm backend edits the process's GPU page tables through libdrm_amdgpu, next to ROCr (DrmVm, hip_vmm.hpp).
+// Before any page is served that way, prove on one slot that (1) the amdgpu_device libdrm handed us drives the SAME
+// address space as ROCr - a GEM_VA map over a VA that ROCr has mapped must be refused, and accepted once ROCr has
+// unmapped it; this step touches no memory, so a wrong VM cannot fault - and (2) data follows the handle: two pages
+// swapped under one VA keep their own contents, seen through HIP's memset/copy on a HIP-registered slot.
+bool drm_self_test(int dev) {
+  if (env_bool("KVCACHED_TEST_FAIL_DRM_SELFTEST", false)) return false; // tests: exercise the fallback
+  std::string why;
+  DrmVm &vm = DrmVm::instance();
+  if (!vm.open(dev, &why)) {
+    KVC_LOG(LOG_WARNING, "direct DRM mapping unavailable: %s", why.c_str());
+    return false;
+  }
+  const size_t ps = kBasePage;
+  void *va = nullptr;
+  hipMemGenericAllocationHandle_t shell = nullptr;
+  hsa_amd_vmem_alloc_handle_t a{}, b{};
+  bool have_a = false, have_b = false, hip_mapped = false, rocr_mapped = false, ok = false;
+  void *drm_mapped = nullptr; // the bo currently mapped at va through DRM
+  auto shootdown = [&]() {
+    void *p = nullptr;
+    if (hipMalloc(&p, kBasePage) == hipSuccess) (void)hipFree(p);
+  };
+  try {
+    const HsaDevice &hd = hsa_device(dev);
+    auto prop = make_alloc_prop(dev, false);
+    if (hipMemAddressReserve(&va, ps, ps, nullptr, 0) != hipSuccess) throw 1;
+    if (hipMemCreate(&shell, ps, &prop, 0) != hipSuccess) throw 2;
+    if (hipMemMap(va, ps, 0, shell, 0) != hipSuccess) throw 3;
+    hip_mapped = true;
+    if (hsa_amd_vmem_unmap(va, ps) != HSA_STATUS_SUCCESS) throw 4;
+    if (hsa_amd_vmem_handle_create(hd.pool, ps, MEMORY_TYPE_PINNED, 0, &a) != HSA_STATUS_SUCCESS) throw 5;
+    have_a = true;
+    if (hsa_amd_vmem_handle_create(hd.pool, ps, MEMORY_TYPE_PINNED, 0, &b) != HSA_STATUS_SUCCESS) throw 6;
+    have_b = true;
+    if (!vm.adopt(a.handle) || !vm.adopt(b.handle)) throw 7;
+    void *bo_a = vm.find(a.handle), *bo_b = vm.find(b.handle);
+    // (1) same address space?
+    if (hsa_amd_vmem_map(va, ps, 0, a, 0) != HSA_STATUS_SUCCESS) throw 8;
+    rocr_mapped = true;
+    hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hd.agent};
+    if (hsa_amd_vmem_set_access(va, ps, &d, 1) != HSA_STATUS_SUCCESS) throw 9;
+    if (vm.map(bo_b, va, ps) == 0) { // accepted: libdrm gave us some other VM
+      (void)vm.unmap(bo_b, va, ps);
+      throw 10;
+    }
+    if (hsa_amd_vmem_unmap(va, ps) != HSA_STATUS_SUCCESS) throw 11;
+    rocr_mapped = false;
+    if (vm.map(bo_b, va, ps) != 0) throw 12;
+    drm_mapped = bo_b;
+    // (2) data follows the handle
+    shootdown();
+    unsigned char host[256];
+    if (hipMemset(va, 0x5a, sizeof host) != hipSuccess || hipDeviceSynchronize() != hipSuccess) throw 13;
+    if (vm.unmap(bo_b, va, ps) != 0) throw 14;
+    drm_mapped = nullptr;
+    if (vm.map(bo_a, va, ps) != 0) throw 15;
+    drm_mapped = bo_a;
+    shootdown();
+    if (hipMemset(va, 0xc3, sizeof host) != hipSuccess || hipDeviceSynchronize() != hipSuccess) throw 16;
+    memset(host, 0, sizeof host);
+    if (hipMemcpy(host, va, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) throw 17;
+    for (unsigned char c : host)
+      if (c != 0xc3) throw 18;
+    if (vm.unmap(bo_a, va, ps) != 0) throw 19;
+    drm_mapped = nullptr;
+    if (vm.map(bo_b, va, ps) != 0) throw 20;
+    drm_mapped = bo_b;
+    shootdown();
+    if (hipMemcpy(host, va, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) throw 21;
+    for (unsigned char c : host)
+      if (c != 0x5a) throw 22;
+    ok = true;
+  } catch (int step) {
+    KVC_LOG(LOG_WARNING, "direct DRM mapping self test stopped at step %d", step);
+  } catch (const std::exception &e) {
+    KVC_LOG(LOG_WARNING, "direct DRM mapping self test: %s", e.what());
+  }
+  (void)hipGetLastError();
+  if (drm_mapped) (void)vm.unmap(drm_mapped, va, ps);
+  if (hip_mapped) { // HIP must find something to unmap
+    if (!rocr_mapped && have_a) rocr_mapped = hsa_amd_vmem_map(va, ps, 0, a, 0) == HSA_STATUS_SUCCESS;
+    if (hipMemUnmap(va, ps) != hipSuccess) {
+      (void)hipGetLastError();
+      if (rocr_mapped) (void)hsa_amd_vmem_unmap(va, ps);
+    }
+  }
+  shootdown();
+  if (have_a) {
+    vm.forget(a.handle);
+    (void)hsa_amd_vmem_handle_release(a);
+  }
+  if (have_b) {
+    vm.forget(b.handle);
+    (void)hsa_amd_vmem_handle_release(b);
+  }
+  if (shell) (void)hipMemRelease(shell);
+  if (va) (void)hipMemAddressFree(va, ps);
+  (void)hipGetLastError();
+  return ok;
+}
 } // namespace
 
 // ------------------------------------------------------------------ registry
@@ -462,8 +564,9 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
     const std::string b = be ? be : "hybrid";
-    if (b != "hip" && b != "hsa" && b != "hybrid") throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip', 'hybrid' or 'hsa'");
-    const int want = b == "hsa" ? kVmmHsa : (b == "hybrid" ? kVmmHybrid : kVmmHip);
+    if (b != "hip" && b != "hsa" && b != "hybrid" && b != "drm")
+      throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip', 'hybrid', 'drm' or 'hsa'");
+    const int want = b == "hsa" ? kVmmHsa : (b == "hybrid" ? kVmmHybrid : (b == "drm" ? kVmmDrm : kVmmHip));
     if (want != vmm_backend().load())
       for (auto &kv : g_contexts) kv.second->drain_pools(); // pooled handles belong to the backend that made them
     vmm_backend() = want;
@@ -478,10 +581,15 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     HIP_CHECK(hipInit(0));
     g_device.index = resolve_dev_index(g_device);
     context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
-    if (vmm_backend() == kVmmHybrid && !hybrid_self_test(g_device.index)) {
+    if (vmm_hip_registered() && !hybrid_self_test(g_device.index)) {
       KVC_LOG(LOG_WARNING, "hybrid VMM backend failed its self test on this HIP runtime: using the plain HIP backend "
                            "(KVCACHED_VMM_BACKEND=hip), map/unmap will be ~2x slower");
       vmm_backend() = kVmmHip;
+    }
+    if (vmm_backend() == kVmmDrm && !drm_self_test(g_device.index)) {
+      KVC_LOG(LOG_WARNING, "direct DRM mapping failed its self test: using the hybrid backend (KVCACHED_VMM_BACKEND=hybrid)");
+      DrmVm::instance().close();
+      vmm_backend() = kVmmHybrid;
     }
   }
   g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout,
@@ -698,10 +806,10 @@ void KvAllocator::backfill_all(KvRegion &r) {
   r.zero.assign(n_zero, phys_handle_t{});
   size_t made = 0;
   try {
-    for (; made < n_zero; ++made) r.zero[made] = vmm_create(ctx_->dev(), r.page_size, false);
+    for (; made < n_zero; ++made) r.zero[made] = vmm_create(ctx_->dev(), r.page_size, false, /*direct=*/false);
     const size_t run = (size_t)std::max<int64_t>(1, options().access_run_slots.load());
     for (size_t i = 0; i < r.num_slots(); ++i) {
-      if (vmm_backend() == kVmmHybrid) register_slot(r, i); // compat promises zeros to ANY access, hipMemcpy included
+      if (vmm_hip_registered()) register_slot(r, i); // compat promises zeros to ANY access, hipMemcpy included
       vmm_map(r.base + i * r.page_size, r.page_size, r.zero_of(i));
     }
     for (size_t i = 0; i < r.num_slots(); i += run) {
@@ -758,7 +866,12 @@ void KvAllocator::unregister_slots(KvRegion &r) {
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.registered[i]) continue;
     char *va = r.base + i * r.page_size;
-    if (!r.mapped[i] && !r.backfilled) { // nothing at the VA on ROCr's side (in compat mode a zero alias is): give HIP something to unmap
+    bool rocr_has_one = r.mapped[i] ? true : r.backfilled; // our page, or in compat mode a zero alias
+    if (r.mapped[i] && vmm_direct_bo(r.handle[i])) {        // drm backend: our page is DRM's mapping, ROCr knows none
+      if (!vmm_try_unmap(va, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
+      rocr_has_one = false;
+    }
+    if (!rocr_has_one) { // give HIP something to unmap
       if (!have_standin) {
         have_standin = hsa_amd_vmem_handle_create(hsa_device(ctx_->dev()).pool, r.page_size, MEMORY_TYPE_PINNED, 0, &standin) ==
                        HSA_STATUS_SUCCESS;
@@ -793,7 +906,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
   if (ctx) (void)hipSetDevice(ctx->dev());
   // Tolerate stale mappings during teardown: log, do not throw (ftensor.cpp:78-98).
   bool whole = false;
-  if (vmm_backend() == kVmmHybrid) {
+  if (vmm_hip_registered()) {
     // HIP unmaps every slot it was told about (that removes our pages' and aliases' mappings too); what was never
     // registered cannot be mapped either
     unregister_slots(r);
@@ -806,7 +919,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.mapped[i]) continue;
     if (!whole) {
-      if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size)) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
+      if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
     dead.push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
@@ -997,7 +1110,7 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     KvRegion &r = *s.region;
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
-    vmm_unmap(r.base + s.index * ps, ps);
+    vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
     *out = Phys{r.handle[s.index], r.seq[s.index]};
@@ -1098,7 +1211,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
-      if (vmm_backend() == kVmmHybrid && !r.registered[s.index]) register_slot(r, s.index); // once per slot
+      if (vmm_hip_registered() && !r.registered[s.index]) register_slot(r, s.index); // once per slot
       if (r.backfilled) vmm_unmap(va, ps);
       int64_t t1 = now_ns();
       bool recycled = false;
@@ -1115,8 +1228,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       phys_handle_t h = ph.h;
       int64_t t2 = now_ns();
+      bool needs_access = true;
       try {
-        vmm_map(va, ps, h);
+        needs_access = vmm_map(va, ps, h);
       } catch (...) {
         if (!imported) pool->release(ph);
         if (r.backfilled && vmm_try_map(va, ps, r.zero_of(s.index))) (void)vmm_try_set_access(va, ps, ctx->dev());
@@ -1130,6 +1244,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       r.seq[s.index] = ph.seq;
       r.mapped[s.index] = imported ? 2 : 1;
       done.push_back(s);
+      if (!needs_access) { // mapped readable+writable in one ioctl (drm backend): straight to the fill queue
+        dirty_tlb = true;
+        if (fill) {
+          pending.push_back(va);
+          launch_pending(false);
+        }
+        continue;
+      }
       if (!(run_len && va == run_start + run_len && run_len < kMaxRunBytes)) {
         flush_run();
         run_start = va;
@@ -1153,7 +1275,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     for (auto it = done.rbegin(); it != done.rend(); ++it) {
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
-      (void)vmm_try_unmap(va, ps);
+      (void)vmm_try_unmap(va, ps, r.handle[it->index]);
       if (r.mapped[it->index] == 1)
         pool->release(Phys{r.handle[it->index], r.seq[it->index]});
       else
@@ -1212,7 +1334,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     }
     char *va = r.base + s.index * ps;
     const int64_t t0 = now_ns();
-    vmm_unmap(va, ps);
+    vmm_unmap(va, ps, r.handle[s.index]);
     const int64_t t1 = now_ns();
     stats().t_unmap += t1 - t0;
     if (r.mapped[s.index] == 1)

@@ -231,6 +231,8 @@ def test_default_backend_is_hybrid_and_falls_back_when_its_self_test_fails(vmm):
     """The default VMM backend registers slots with HIP once and drives them through ROCr; plain HIP
     copies keep working on such memory. If the self test at init fails (forced here), the plain HIP backend is used
     and everything still works, only slower."""
+    if os.environ.get("KVCACHED_VMM_BACKEND", "hybrid") != "hybrid":
+        pytest.skip("the suite is being run with another backend forced through the environment")
     ops, capi, ts = _setup(vmm, layers=1, per_layer=16 * MiB, backfill=False, kv=1, unified=True)
     assert capi.get_option(108) == 2                                   # hybrid
     epp = PAGE // 2
@@ -251,6 +253,52 @@ def test_default_backend_is_hybrid_and_falls_back_when_its_self_test_fails(vmm):
     ts = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 1, 0, True)
     assert ops.map_to_kv_tensors([PAGE])
     assert int(torch.count_nonzero(ts[0][epp:2 * epp])) == 0
+    assert ops.unmap_from_kv_tensors([PAGE])
+
+
+def test_drm_backend_one_ioctl_per_map_and_its_fallback(vmm, monkeypatch):
+    """KVCACHED_VMM_BACKEND=drm: own pages are mapped with one DRM_AMDGPU_GEM_VA ioctl on a buffer
+    object imported once per handle. Same observable behaviour as hybrid: zero-filled pages, HIP copies in and out,
+    contents follow the physical page when slots are re-backed from the pool, handle ledger balanced; in compat mode
+    the aliases (ROCr's) and the pages (DRM's) take turns at the same VA. A failing self test means hybrid."""
+    monkeypatch.setenv("KVCACHED_VMM_BACKEND", "drm")
+    for backfill in (False, True):
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=backfill, kv=1, unified=True)
+        assert capi.get_option(108) == 3
+        capi.reset_stats()
+        epp = PAGE // 2
+        t = ts[0]
+        if backfill:
+            assert int(torch.count_nonzero(t[5 * epp:6 * epp])) == 0   # an alias of a zero page
+        offs = [i * PAGE for i in (0, 3, 4, 9, 31)]
+        assert ops.map_to_kv_tensors(offs)
+        for k, i in enumerate((0, 3, 4, 9, 31)):
+            assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0
+            t[i * epp:(i + 1) * epp].fill_(100 + k)
+        torch.cuda.synchronize()
+        assert t[3 * epp:3 * epp + 4].cpu().tolist() == [101] * 4       # hipMemcpy D2H straight from the KV tensor
+        t[9 * epp:9 * epp + 4] = torch.tensor([1, 2, 3, 4], dtype=torch.int16)
+        assert t[9 * epp:9 * epp + 4].clone().cpu().tolist() == [1, 2, 3, 4]
+        ops.map_to_kv_tensors([3 * PAGE])                               # double map: logged and skipped, like the reference
+        assert t[3 * epp:3 * epp + 4].cpu().tolist() == [101] * 4
+        assert ops.unmap_from_kv_tensors(offs)
+        if backfill:
+            assert int(torch.count_nonzero(t[3 * epp:4 * epp])) == 0   # the alias is back
+        # the same five handles come back from the pool under other VAs: zero-filled, nothing stale shines through
+        offs2 = [i * PAGE for i in (7, 8, 20, 21, 22, 23)]
+        assert ops.map_to_kv_tensors(offs2)
+        for i in (7, 8, 20, 21, 22, 23):
+            assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0
+        st = capi.get_stats()
+        assert st["handles_reused"] >= 5 and st["pages_mapped"] == 11
+        assert ops.unmap_from_kv_tensors(offs2)
+        ops.shutdown_kvcached()
+        st = capi.get_stats()
+        assert st["handles_created"] == st["handles_released"]
+    monkeypatch.setenv("KVCACHED_TEST_FAIL_DRM_SELFTEST", "1")
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=16 * MiB, backfill=False, kv=1, unified=True)
+    assert capi.get_option(108) == 2                                   # hybrid
+    assert ops.map_to_kv_tensors([PAGE]) and int(torch.count_nonzero(ts[0][PAGE // 2:PAGE])) == 0
     assert ops.unmap_from_kv_tensors([PAGE])
 
 
