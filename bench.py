@@ -57,8 +57,9 @@ def parse_args():
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", choices=["hip", "hybrid", "drm", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "hybrid"),
-                    help="VMM backend of the main measurement (DESIGN.md §4.6)")
+    ap.add_argument("--backend", choices=["hip", "hybrid", "drm", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "drm"),
+                    help="VMM backend requested for the main measurement (library default: drm; DESIGN.md §4.6/§4.7); the line "
+                         "reports the one in effect after the library's self tests")
     return ap.parse_args()
 
 
@@ -75,7 +76,7 @@ class Pool:
     """One region of `window` batches, driven through the C ABI."""
 
     def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
-                 compound_layers: int = 0, backend: str = "hybrid"):
+                 compound_layers: int = 0, backend: str = "drm"):
         self.capi, self.device, self.window = capi, device, window_batches
         os.environ["KVCACHED_VMM_BACKEND"] = "hsa" if backend.startswith("hsa") else backend
         os.environ["KVCACHED_HSA_CPU_ACCESS"] = "false" if backend == "hsa_kernels_only" else "true"
@@ -116,7 +117,7 @@ def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
 
 
 def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=None, sync=None, compound_layers=0,
-            burst=False, prefault=True, backend="hybrid", page=PAGE):
+            burst=False, prefault=True, backend="drm", page=PAGE):
     """cycle (default): every step maps+zeroes one batch and unmaps it again. burst=True: `steps` batches are
     backed one after the other and only unmapped after the timed region.
     prefault: as in the bench_vmm protocol (warm-up sweeps over the whole window before the timed sweeps), every batch
@@ -172,7 +173,8 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
                 unmapper(batch_offsets((warmup + i) % window, slot=slot))
                 per_unmap.append(time.perf_counter() - tb)
         return {"elapsed": elapsed, "per_step": per_map, "per_unmap": per_unmap, "stats": st, "reserve_s": pool.reserve_s,
-                "window_GiB": pool.size / GiB, "burst": burst}
+                "window_GiB": pool.size / GiB, "burst": burst,
+                "backend_in_effect": {0: "hip", 1: "hsa", 2: "hybrid", 3: "drm"}.get(int(capi.get_option(108)), "?")}
     finally:
         pool.close()
 
@@ -427,7 +429,7 @@ def main():
             "config": {"workload": "bench_vmm: 64 GiB VA window (one untimed warm-up sweep over the window during set-up, as in "
                                    "the protocol); step = map+zero then unmap one batch of 1024 x 2 MiB "
                                    "pages (shuffled offsets), both halves timed",
-                       "mode": args.mode, "vmm_backend": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
+                       "mode": args.mode, "vmm_backend": res["backend_in_effect"], "vmm_backend_requested": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
             "map_zero_GBps": round(main_sum["map_zero_GBps"], 2),
@@ -445,6 +447,7 @@ def main():
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
+                        ("hybrid_backend_same_cycle", "lazy", None, 0, False, True),
                         ("hip_backend_same_cycle", "lazy", None, 0, False, True),
                         ("hip_backend_compat_zero_backfill_sharded", "compat", None, 0, False, True),
                         ("hsa_backend_cpu_accessible", "lazy", None, 0, False, True),
@@ -456,10 +459,10 @@ def main():
                         ("page_size_8MiB_instead_of_2MiB", "lazy", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
-                        nsteps = 24 if (burst or name.startswith("fresh_va") or name == "hip_backend_same_cycle") else 8
+                        nsteps = 24 if (burst or name.startswith("fresh_va") or name.endswith("_backend_same_cycle")) else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
                                      backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
-                                     else ("hip" if name.startswith("hip_") else args.backend),
+                                     else ("hip" if name.startswith("hip_") else ("hybrid" if name.startswith("hybrid_") else args.backend)),
                                      page=8 * MiB if name.startswith("page_size_8MiB") else PAGE)
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])

@@ -1,0 +1,157 @@
+"""Soak of the whole hot path with the data checked: random alloc / free / trim / resize against a live
+KVCacheManager on one MI355X, every block signed in every layer's K and V when it is handed out and verified just
+before it is given back. A stale translation, a page mapped under the wrong slot or a handle recycled while still
+visible shows up as a wrong signature; a leak shows up in the handle ledger at the end.
+
+    python benchmarks/soak_manager.py --seconds 60 [--backend drm|hybrid|hip] [--async-unmap] [--compat] [--prealloc]
+
+Prints one JSON line. Exit code 1 on any mismatch."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+PAGE = 2 << 20
+LAYERS, BLOCK_TOKENS, CELL = 4, 16, 2048                       # 32 KiB blocks, 64 per page; a page id = 8 slots
+BLOCK_BYTES = BLOCK_TOKENS * CELL
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--backend", default=None)
+    ap.add_argument("--async-unmap", action="store_true")
+    ap.add_argument("--compat", action="store_true", help="KVCACHED_ZERO_BACKFILL=true (the reference's aliasing)")
+    ap.add_argument("--prealloc", action="store_true", help="prealloc + watcher threads on")
+    ap.add_argument("--page-ids", type=int, default=1024, help="virtual pool size in page ids (16 MiB each)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    if args.backend:
+        os.environ["KVCACHED_VMM_BACKEND"] = args.backend
+    os.environ["KVCACHED_ASYNC_UNMAP"] = "true" if args.async_unmap else "false"
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if args.compat else "false"
+    os.environ["KVCACHED_PAGE_PREALLOC_ENABLED"] = "true" if args.prealloc else "false"
+    os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_soak_{os.getpid()}")
+    os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    import torch
+
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    from kvcached_amd.cli.utils import update_kv_cache_limit
+
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    vmm_ops.init_kvcached(dev, PAGE, False)
+    backend = {0: "hip", 1: "hsa", 2: "hybrid", 3: "drm"}[capi.get_option(108)]
+    blocks_per_page = PAGE // BLOCK_BYTES
+    num_blocks = args.page_ids * blocks_per_page
+    per_layer = num_blocks * BLOCK_BYTES * 2                   # K half + V half
+    ts = vmm_ops.create_kv_tensors(per_layer, 1, dev, LAYERS, 2, 0, False)
+    words = [t.view(torch.int64) for t in ts]                  # signatures are int64 words
+    v_off = per_layer // 2 // 8
+    m = kcm.KVCacheManager(num_blocks=num_blocks, block_size=BLOCK_TOKENS, cell_size=CELL, num_layers=LAYERS)
+    assert m._post_init_done.wait(30)
+    ipc = m.page_allocator._ipc_name()
+    full_limit = per_layer * LAYERS
+    rng = np.random.default_rng(args.seed)
+    live = {}                                                   # request id -> (block ids tensor on the GPU, n)
+    next_rid = 1
+    counts = dict(alloc=0, alloc_refused=0, free=0, trim=0, resize=0, blocks_signed=0, blocks_verified=0)
+    bad = 0
+    # each block carries its signature in its first AND last word (a block may straddle nothing, but a 2 MiB page
+    # holds 64 of them: both ends of every page get covered)
+    last = BLOCK_BYTES // 8 - 1
+
+    def sign(ids_t, rid):
+        sig = (rid << 24) + ids_t
+        base = ids_t * (BLOCK_BYTES // 8)
+        for layer, w in enumerate(words):
+            val = sig + (layer << 56)
+            w[base] = val
+            w[base + last] = val
+            w[v_off + base] = ~val
+            w[v_off + base + last] = ~val
+
+    def verify(ids_t, rid):
+        sig = (rid << 24) + ids_t
+        base = ids_t * (BLOCK_BYTES // 8)
+        wrong = torch.zeros((), dtype=torch.int64, device=dev)
+        for layer, w in enumerate(words):
+            val = sig + (layer << 56)
+            wrong += (w[base] != val).sum() + (w[base + last] != val).sum()
+            wrong += (w[v_off + base] != ~val).sum() + (w[v_off + base + last] != ~val).sum()
+        return int(wrong)
+
+    def free_one(rid):
+        nonlocal bad
+        ids_t, ids = live.pop(rid)
+        w = verify(ids_t, rid)
+        if w:
+            bad += w
+            print(f"[soak] request {rid}: {w} signature words wrong over {len(ids)} blocks", file=sys.stderr)
+        counts["blocks_verified"] += len(ids)
+        m.free(ids)
+        counts["free"] += 1
+
+    t_end = time.time() + args.seconds
+    shrunk = False
+    while time.time() < t_end and not bad:
+        r = rng.random()
+        held = sum(len(v[1]) for v in live.values())
+        if r < 0.50 or not live:
+            n = int(rng.integers(1, 4000)) if rng.random() < 0.8 else int(rng.integers(1, 40))
+            ids = m.alloc(n)
+            if ids is None:
+                counts["alloc_refused"] += 1
+                if live:
+                    free_one(next(iter(live)))
+                continue
+            ids_t = torch.tensor(ids, dtype=torch.int64, device=dev)
+            sign(ids_t, next_rid)
+            live[next_rid] = (ids_t, ids)
+            next_rid += 1
+            counts["alloc"] += 1
+            counts["blocks_signed"] += n
+        elif r < 0.93:
+            keys = list(live)
+            free_one(keys[int(rng.integers(len(keys)))])
+        elif r < 0.96:
+            m.trim()
+            counts["trim"] += 1
+        elif args.prealloc:                                    # the watcher applies limits written to the shm record
+            shrunk = not shrunk
+            from contextlib import redirect_stdout
+            with open(os.devnull, "w") as devnull, redirect_stdout(devnull):
+                update_kv_cache_limit(ipc, full_limit // 2 if shrunk else full_limit)
+            counts["resize"] += 1
+        else:
+            m.available_size()
+        if held > num_blocks * 0.6:                            # keep the pool from saturating: drop a few requests
+            for rid in list(live)[:3]:
+                free_one(rid)
+    for rid in list(live):
+        free_one(rid)
+    torch.cuda.synchronize()
+    m.trim()
+    capi.flush_unmaps()
+    inuse = m.page_allocator.get_num_inuse_pages()
+    st = capi.get_stats()
+    del m
+    vmm_ops.shutdown_kvcached()
+    end = capi.get_stats()
+    leak = end["handles_created"] - end["handles_released"]
+    out = dict(backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
+               prealloc=args.prealloc, **counts, wrong_words=bad, inuse_pages_at_end=inuse,
+               pages_mapped=st["pages_mapped"], pages_unmapped=st["pages_unmapped"],
+               handles_created=end["handles_created"], handles_reused=end["handles_reused"], handle_leak=leak)
+    print(json.dumps(out))
+    return 1 if (bad or leak or inuse) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

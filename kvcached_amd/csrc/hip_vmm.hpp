@@ -2,15 +2,16 @@
 //
 // Two APIs reach the same driver: HIP's (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess /
 // hipMemUnmap / hipMemRelease) and ROCr's (hsa_amd_vmem_*), which HIP sits on. Every verb below exists in both
-// forms; KVCACHED_VMM_BACKEND picks the combination (hybrid, hip, hsa - see the comment above vmm_backend()).
+// forms; KVCACHED_VMM_BACKEND picks the combination (drm, hybrid, hip, hsa - see the comment above vmm_backend()).
 // No CUDA branch anywhere (the reference's csrc/inc/gpu_vmm.hpp is a CUDA/HIP dual shim - this is not).
 // Measured costs on MI355X / ROCm 7.2 that shaped the design (profiles/r01_*), per 2 MiB mapping:
 //   HIP : create 3.4 us | map 3.1 us | set_access 3.3 us | unmap 12-15 us (10 of them a GPU-marker spin) | release 3-50 us
 //   ROCr: create 3.3 us | map 2.3 us | set_access 3.0 us | unmap 2.8 us
 //   creation is O(live handles) in ROCr's user space with either; the cost is per MAPPING, not per byte; no call
 //   scales across threads of one process; no partial unmap and no working map offset.
+//   DRM : (buffer object imported once per handle) map 2.2 us, no set_access | unmap 2.1 us   - DrmVm below
 // Hence: recycle handles (PhysPool), never touch a slot twice, one batch per call with the fill kernel overlapped,
-// and unmap through ROCr on VA that HIP has been introduced to once.
+// and map/unmap with one GEM_VA ioctl each on VA that HIP has been introduced to once.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -563,7 +563,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
-    const std::string b = be ? be : "hybrid";
+    const std::string b = be ? be : "drm";
     if (b != "hip" && b != "hsa" && b != "hybrid" && b != "drm")
       throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip', 'hybrid', 'drm' or 'hsa'");
     const int want = b == "hsa" ? kVmmHsa : (b == "hybrid" ? kVmmHybrid : (b == "drm" ? kVmmDrm : kVmmHip));

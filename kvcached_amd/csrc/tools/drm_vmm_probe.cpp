@@ -274,6 +274,7 @@ int main(int argc, char **argv) {
   CK(hipStreamSynchronize(s));
   printf("hipMemcpy H2D into them, checked by a kernel: %llu words wrong\n", bad);
   CK(hipMemset(va, 0, (size_t)kReg * PAGE));
+  CK(hipDeviceSynchronize()); // hipMemset on device memory is asynchronous, and `s` does not wait for the null stream
   for (int i = 0; i < kReg; i++) host_tags[i] = 0;
   CK(hipMemcpyAsync(tags, host_tags.data(), kReg * sizeof(unsigned), hipMemcpyHostToDevice, s));
   CK(hipMemsetAsync(cnt, 0, 8, s));

@@ -227,33 +227,27 @@ def test_async_unmap_queue_reclaimer_and_rebacking(vmm):
     capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
 
 
-def test_default_backend_is_hybrid_and_falls_back_when_its_self_test_fails(vmm):
-    """The default VMM backend registers slots with HIP once and drives them through ROCr; plain HIP
-    copies keep working on such memory. If the self test at init fails (forced here), the plain HIP backend is used
-    and everything still works, only slower."""
-    if os.environ.get("KVCACHED_VMM_BACKEND", "hybrid") != "hybrid":
-        pytest.skip("the suite is being run with another backend forced through the environment")
-    ops, capi, ts = _setup(vmm, layers=1, per_layer=16 * MiB, backfill=False, kv=1, unified=True)
-    assert capi.get_option(108) == 2                                   # hybrid
+def test_default_backend_and_its_fallback_chain(vmm, monkeypatch):
+    """Default: drm (own pages mapped with one GEM_VA ioctl) on top of hybrid (slots registered with
+    HIP once, everything else through ROCr, §4.6); plain HIP copies keep working on such memory. Each layer is checked
+    by a self test at init: drm falls back to hybrid, hybrid to plain HIP (forced here) - everything still works,
+    only slower."""
+    monkeypatch.delenv("KVCACHED_VMM_BACKEND", raising=False)
     epp = PAGE // 2
-    assert ops.map_to_kv_tensors([0, 3 * PAGE])
-    ts[0][:epp].fill_(321)
-    torch.cuda.synchronize()
-    assert ts[0][:4].cpu().tolist() == [321] * 4                        # hipMemcpy D2H straight from the KV tensor
-    ts[0][3 * epp:3 * epp + 4] = torch.tensor([1, 2, 3, 4], dtype=torch.int16)   # H2D into it
-    assert ts[0][3 * epp:3 * epp + 4].clone().cpu().tolist() == [1, 2, 3, 4]     # D2D out of it
-    assert ops.unmap_from_kv_tensors([0, 3 * PAGE])
-    ops.shutdown_kvcached()
-    os.environ["KVCACHED_TEST_FAIL_HYBRID_SELFTEST"] = "1"
-    try:
-        ops.init_kvcached(DEV, PAGE, False)
-    finally:
-        os.environ.pop("KVCACHED_TEST_FAIL_HYBRID_SELFTEST")
-    assert capi.get_option(108) == 0                                   # fell back to plain HIP
-    ts = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 1, 0, True)
-    assert ops.map_to_kv_tensors([PAGE])
-    assert int(torch.count_nonzero(ts[0][epp:2 * epp])) == 0
-    assert ops.unmap_from_kv_tensors([PAGE])
+    for hook, want in ((None, 3), ("KVCACHED_TEST_FAIL_DRM_SELFTEST", 2), ("KVCACHED_TEST_FAIL_HYBRID_SELFTEST", 0)):
+        if hook:
+            monkeypatch.setenv(hook, "1")
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=16 * MiB, backfill=False, kv=1, unified=True)
+        assert capi.get_option(108) == want
+        assert ops.map_to_kv_tensors([0, 3 * PAGE])
+        assert int(torch.count_nonzero(ts[0][3 * epp:4 * epp])) == 0
+        ts[0][:epp].fill_(321)
+        torch.cuda.synchronize()
+        assert ts[0][:4].cpu().tolist() == [321] * 4                        # hipMemcpy D2H straight from the KV tensor
+        ts[0][3 * epp:3 * epp + 4] = torch.tensor([1, 2, 3, 4], dtype=torch.int16)   # H2D into it
+        assert ts[0][3 * epp:3 * epp + 4].clone().cpu().tolist() == [1, 2, 3, 4]     # D2D out of it
+        assert ops.unmap_from_kv_tensors([0, 3 * PAGE])
+        ops.shutdown_kvcached()
 
 
 def test_drm_backend_one_ioctl_per_map_and_its_fallback(vmm, monkeypatch):
