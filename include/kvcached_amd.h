@@ -96,7 +96,11 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              effect (0 hip, 1 hsa, 2 hybrid, 3 drm). drm = hybrid, and this process's own
  *                              pages are mapped/unmapped with one DRM_AMDGPU_GEM_VA ioctl each through
  *                              libdrm_amdgpu on buffer objects imported once per handle (2.2 + 2.1 us per page
- *                              instead of 5.3 + 2.8); self-tested at kvc_init, falls back to hybrid. DESIGN.md §4.6/§4.7.
+ *                              instead of 5.3 + 2.8); self-tested at kvc_init, falls back to hybrid. With drm, physical
+ *                              pages are also allocated straight from KFD (AMDKFD_IOC_ALLOC_MEMORY_OF_GPU on the
+ *                              library's own fd of /dev/kfd: 5 us flat instead of the runtime's O(live handles);
+ *                              KVCACHED_DRM_KFD_CREATE=false keeps ROCr's creation; kvc_get_option(110) = 1 when active).
+ *                              DESIGN.md §4.6/§4.7.
  *   KVC_OPT_ASYNC_UNMAP    1 = kvc_unmap_from_kv_tensors only marks the slots and queues them; a reclaimer thread
  *                              of the library carries out hipMemUnmap + invalidation + handle recycling in small
  *                              chunks, yielding to map calls. A slot that is mapped again before its turn is kept

@@ -23,6 +23,8 @@
 #include <fcntl.h>
 #include <limits.h>
 #include <strings.h>
+#include <sys/ioctl.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -265,21 +267,103 @@ public:
     const int r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, (uint32_t)dmabuf, &res) : -ENODEV;
     ::close(dmabuf);
     if (r != 0 || !res.bo) return false;
-    bo_[h] = res.bo;
+    bo_[h] = Entry{res.bo, false};
     return true;
   }
   void *find(phys_handle_t h) {
     std::lock_guard<std::mutex> g(mu_);
     auto it = bo_.find(h);
-    return it == bo_.end() ? nullptr : it->second;
+    return it == bo_.end() ? nullptr : it->second.bo;
   }
-  // Before the ROCr handle is released: drop DRM's reference.
-  void forget(phys_handle_t h) {
+  // Drops DRM's reference; a buffer of our own making (create()) is given back to KFD as well. Returns whether the
+  // handle was ours alone (nothing left for ROCr to release).
+  bool forget(phys_handle_t h) {
+    Entry e{};
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = bo_.find(h);
+      if (it == bo_.end()) return false;
+      e = it->second;
+      bo_.erase(it);
+    }
+    (void)api_.bo_free(e.bo);
+    if (!e.kfd) return false;
+    KfdFree f{h};
+    if (kfd_ioctl(kKfdFree, &f) != 0) KVC_LOG(LOG_ERROR, "AMDKFD_IOC_FREE_MEMORY_OF_GPU failed: %s", strerror(errno));
+    return true;
+  }
+
+  // ---- physical memory straight from KFD. hipMemCreate and hsa_amd_vmem_handle_create cost O(live handles) in the
+  // runtime's user space (9 -> 146 us at 32k handles) around an ioctl that is flat (1.5 us, tools/kfd_alloc_probe.cpp);
+  // with mapping already off the runtime's hands nothing else needs its handle. KFD attaches every open of /dev/kfd
+  // by one process to the same kfd_process, so a buffer allocated on our fd lives in the same context as ROCr's.
+  bool kfd_ready() const { return kfd_fd_ >= 0 && gpu_id_ != 0; }
+  void disable_kfd() {
     std::lock_guard<std::mutex> g(mu_);
-    auto it = bo_.find(h);
-    if (it == bo_.end()) return;
-    (void)api_.bo_free(it->second);
-    bo_.erase(it);
+    if (kfd_fd_ >= 0) ::close(kfd_fd_);
+    kfd_fd_ = -1;
+  }
+  // Opens /dev/kfd and looks up KFD's id of the device (sysfs topology, matched by PCI address).
+  bool open_kfd(std::string *why) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (kfd_fd_ >= 0 && gpu_id_) return true;
+    char bdf[64] = {0};
+    unsigned dom = 0, bus = 0, dv = 0, fn = 0;
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, hip_dev_) != hipSuccess || sscanf(bdf, "%x:%x:%x.%x", &dom, &bus, &dv, &fn) != 4) {
+      (void)hipGetLastError();
+      *why = "no PCI address for the device";
+      return false;
+    }
+    gpu_id_ = kfd_gpu_id_for(dom, bus, dv, fn);
+    if (!gpu_id_) {
+      *why = std::string("no KFD topology node for ") + bdf;
+      return false;
+    }
+    kfd_fd_ = ::open("/dev/kfd", O_RDWR | O_CLOEXEC);
+    if (kfd_fd_ < 0) {
+      *why = std::string("cannot open /dev/kfd: ") + strerror(errno);
+      return false;
+    }
+    return true;
+  }
+  // One buffer of `size` bytes of this GPU's memory, imported into DRM: {handle, bo}. Throws GpuError.
+  phys_handle_t create(size_t size) {
+    KfdAlloc a{};
+    a.size = size;
+    a.gpu_id = gpu_id_;
+    a.flags = kKfdVramFlags;
+    if (kfd_ioctl(kKfdAlloc, &a) != 0)
+      throw GpuError(std::string("AMDKFD_IOC_ALLOC_MEMORY_OF_GPU failed: ") + (errno == ENOMEM ? "out of memory" : strerror(errno)));
+    KfdExport e{};
+    e.handle = a.handle;
+    e.flags = O_CLOEXEC | O_RDWR;
+    ImportResult res{};
+    int r = kfd_ioctl(kKfdExport, &e) != 0 ? -errno : 0;
+    if (r == 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, e.dmabuf_fd, &res) : -ENODEV;
+      ::close((int)e.dmabuf_fd);
+      if (r == 0 && res.bo) bo_[a.handle] = Entry{res.bo, true};
+    }
+    if (r != 0 || !res.bo) {
+      KfdFree f{a.handle};
+      (void)kfd_ioctl(kKfdFree, &f);
+      throw GpuError(std::string("exporting a KFD buffer into DRM failed: ") + strerror(r < 0 ? -r : EIO));
+    }
+    return a.handle;
+  }
+  // A dmabuf fd of a buffer made by create() (for the cross-process pool); -1 if `h` is not one.
+  int export_fd(phys_handle_t h) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = bo_.find(h);
+      if (it == bo_.end() || !it->second.kfd) return -1;
+    }
+    KfdExport e{};
+    e.handle = h;
+    e.flags = O_CLOEXEC | O_RDWR;
+    if (kfd_ioctl(kKfdExport, &e) != 0) throw GpuError(std::string("AMDKFD_IOC_EXPORT_DMABUF failed: ") + strerror(errno));
+    return (int)e.dmabuf_fd;
   }
   size_t adopted() {
     std::lock_guard<std::mutex> g(mu_);
@@ -294,6 +378,57 @@ private:
     void *bo;
     uint64_t alloc_size;
   };
+  struct Entry {
+    void *bo;  // amdgpu_bo_handle
+    bool kfd;  // allocated by create(): the key is KFD's handle, not ROCr's
+  };
+  // include/uapi/linux/kfd_ioctl.h, restated (the image's header predates EXPORT_DMABUF)
+  struct KfdAlloc { // kfd_ioctl_alloc_memory_of_gpu_args
+    uint64_t va_addr, size, handle, mmap_offset;
+    uint32_t gpu_id, flags;
+  };
+  struct KfdFree { // kfd_ioctl_free_memory_of_gpu_args
+    uint64_t handle;
+  };
+  struct KfdExport { // kfd_ioctl_export_dmabuf_args
+    uint64_t handle;
+    uint32_t flags, dmabuf_fd;
+  };
+  static constexpr unsigned long kKfdAlloc = _IOWR('K', 0x16, KfdAlloc), kKfdFree = _IOW('K', 0x17, KfdFree),
+                                 kKfdExport = _IOWR('K', 0x24, KfdExport);
+  // VRAM | WRITABLE | PUBLIC | NO_SUBSTITUTE, va 0: exactly what ROCr passes for hsa_amd_vmem_handle_create on the
+  // coarse-grained device pool (its calls logged by tools/kfd_alloc_probe.cpp, profiles/r01_kfd_alloc_probe.log)
+  static constexpr uint32_t kKfdVramFlags = (1u << 31) | (1u << 29) | (1u << 28) | 1u;
+  int kfd_ioctl(unsigned long req, void *arg) {
+    int r;
+    do r = (int)syscall(SYS_ioctl, kfd_fd_, req, arg);
+    while (r == -1 && (errno == EINTR || errno == EAGAIN)); // as the thunk does
+    return r;
+  }
+  static uint32_t kfd_gpu_id_for(unsigned domain, unsigned bus, unsigned dev, unsigned fn) {
+    const unsigned long long want = (bus << 8) | (dev << 3) | fn;
+    for (int n = 0; n < 256; n++) {
+      char path[128];
+      snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
+      FILE *f = fopen(path, "r");
+      if (!f) break;
+      unsigned long id = 0;
+      if (fscanf(f, "%lu", &id) != 1) id = 0;
+      fclose(f);
+      if (!id) continue; // a CPU node
+      snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+      if (!(f = fopen(path, "r"))) continue;
+      char key[64];
+      unsigned long long val, loc = ~0ull, dom = 0;
+      while (fscanf(f, "%63s %llu", key, &val) == 2) {
+        if (!strcmp(key, "location_id")) loc = val;
+        if (!strcmp(key, "domain")) dom = val;
+      }
+      fclose(f);
+      if (loc == want && dom == domain) return (uint32_t)id;
+    }
+    return 0;
+  }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
   static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2; // AMDGPU_VA_OP_MAP / _UNMAP
   struct Api {
@@ -340,8 +475,17 @@ private:
     return found;
   }
   void close_locked() {
-    for (auto &kv : bo_) (void)api_.bo_free(kv.second);
+    for (auto &kv : bo_) {
+      (void)api_.bo_free(kv.second.bo);
+      if (kv.second.kfd) {
+        KfdFree f{kv.first};
+        (void)kfd_ioctl(kKfdFree, &f);
+      }
+    }
     bo_.clear();
+    if (kfd_fd_ >= 0) ::close(kfd_fd_);
+    kfd_fd_ = -1;
+    gpu_id_ = 0;
     if (dev_) (void)api_.device_deinitialize(dev_);
     dev_ = nullptr;
     if (fd_ >= 0) ::close(fd_);
@@ -353,7 +497,9 @@ private:
   Api api_;
   void *dev_ = nullptr; // amdgpu_device_handle
   int fd_ = -1, hip_dev_ = -1;
-  std::unordered_map<phys_handle_t, void *> bo_; // ROCr handle -> amdgpu_bo_handle
+  int kfd_fd_ = -1;      // our own open of /dev/kfd (same kfd_process as ROCr's)
+  uint32_t gpu_id_ = 0;  // KFD's id of the device
+  std::unordered_map<phys_handle_t, Entry> bo_; // ROCr handle or KFD handle -> buffer object
 };
 
 inline hipMemAllocationProp make_alloc_prop(int dev, bool exportable) {
@@ -391,6 +537,8 @@ inline bool vmm_try_address_free(void *va, size_t size) {
 // (false for handles that are mapped many times over - the zero aliases - which stay with ROCr).
 inline phys_handle_t vmm_create(int dev, size_t size, bool exportable, bool direct = true) {
   if (vmm_uses_rocr()) {
+    if (direct && vmm_backend() == kVmmDrm && DrmVm::instance().hip_dev() == dev && DrmVm::instance().kfd_ready())
+      return DrmVm::instance().create(size); // flat 5 us instead of O(live handles)
     hsa_amd_vmem_alloc_handle_t h{};
     HSA_CHECK(hsa_amd_vmem_handle_create(hsa_device(dev).pool, size, MEMORY_TYPE_PINNED, 0, &h));
     if (direct && vmm_backend() == kVmmDrm && DrmVm::instance().hip_dev() == dev && !DrmVm::instance().adopt(h.handle)) {
@@ -405,7 +553,7 @@ inline phys_handle_t vmm_create(int dev, size_t size, bool exportable, bool dire
   return reinterpret_cast<phys_handle_t>(h);
 }
 inline bool vmm_try_release(phys_handle_t h) {
-  if (vmm_backend() == kVmmDrm) DrmVm::instance().forget(h);
+  if (vmm_backend() == kVmmDrm && DrmVm::instance().forget(h)) return true; // a buffer of our own: ROCr never saw it
   if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }

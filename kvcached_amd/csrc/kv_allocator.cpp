@@ -502,6 +502,47 @@ bool drm_self_test(int dev) {
     for (unsigned char c : host)
       if (c != 0x5a) throw 22;
     ok = true;
+    // (3) optional on top: physical memory straight from KFD (flat creation cost). Its failure only means that
+    // handles keep coming from ROCr.
+    if (vm.unmap(bo_b, va, ps) != 0) throw 23;
+    drm_mapped = nullptr;
+    bool kfd_ok = false;
+    if (env_bool("KVCACHED_DRM_KFD_CREATE", true) && !env_bool("KVCACHED_TEST_FAIL_KFD_SELFTEST", false)) {
+      std::string why_kfd;
+      phys_handle_t k = 0;
+      int step = 0;
+      try {
+        if (!vm.open_kfd(&why_kfd)) throw 1;
+        k = vm.create(ps);
+        void *bo_k = vm.find(k);
+        if (!bo_k || vm.map(bo_k, va, ps) != 0) throw 2;
+        drm_mapped = bo_k;
+        shootdown();
+        if (hipMemset(va, 0x77, sizeof host) != hipSuccess || hipDeviceSynchronize() != hipSuccess) throw 3;
+        if (hipMemcpy(host, va, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) throw 4;
+        for (unsigned char c : host)
+          if (c != 0x77) throw 5;
+        if (vm.unmap(bo_k, va, ps) != 0) throw 6;
+        drm_mapped = nullptr;
+        shootdown();
+        kfd_ok = true;
+      } catch (int st) {
+        step = st;
+      } catch (const std::exception &e) {
+        why_kfd = e.what();
+        step = -1;
+      }
+      (void)hipGetLastError();
+      if (drm_mapped) {
+        (void)vm.unmap(drm_mapped, va, ps);
+        drm_mapped = nullptr;
+      }
+      if (k) (void)vm.forget(k);
+      if (!kfd_ok)
+        KVC_LOG(LOG_WARNING, "physical pages straight from KFD unavailable (step %d%s%s): creating them through ROCr", step,
+                why_kfd.empty() ? "" : ": ", why_kfd.c_str());
+    }
+    if (!kfd_ok) vm.disable_kfd();
   } catch (int step) {
     KVC_LOG(LOG_WARNING, "direct DRM mapping self test stopped at step %d", step);
   } catch (const std::exception &e) {
@@ -1441,10 +1482,12 @@ int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out
   for (auto &s : slots) {
     if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
     int fd = -1;
-    if (vmm_uses_rocr())
-      HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
-    else
+    if (vmm_uses_rocr()) {
+      if (vmm_backend() == kVmmDrm) fd = DrmVm::instance().export_fd(s.region->handle[s.index]); // -1: a ROCr handle
+      if (fd < 0) HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
+    } else {
       HIP_CHECK(hipMemExportToShareableHandle(&fd, as_hip(s.region->handle[s.index]), hipMemHandleTypePosixFileDescriptor, 0));
+    }
     out_fds[k++] = fd;
   }
   return k;

@@ -256,9 +256,13 @@ def test_drm_backend_one_ioctl_per_map_and_its_fallback(vmm, monkeypatch):
     contents follow the physical page when slots are re-backed from the pool, handle ledger balanced; in compat mode
     the aliases (ROCr's) and the pages (DRM's) take turns at the same VA. A failing self test means hybrid."""
     monkeypatch.setenv("KVCACHED_VMM_BACKEND", "drm")
-    for backfill in (False, True):
+    for backfill, kfd_create in ((False, True), (True, True), (False, False), (False, "selftest fails")):
+        monkeypatch.setenv("KVCACHED_DRM_KFD_CREATE", "false" if kfd_create is False else "true")
+        if kfd_create == "selftest fails":
+            monkeypatch.setenv("KVCACHED_TEST_FAIL_KFD_SELFTEST", "1")
         ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=backfill, kv=1, unified=True)
         assert capi.get_option(108) == 3
+        assert capi.get_option(110) == int(kfd_create is True)         # physical pages straight from KFD, or via ROCr
         capi.reset_stats()
         epp = PAGE // 2
         t = ts[0]
