@@ -32,6 +32,7 @@ struct Options {
   std::atomic<int64_t> pool_idle_ms{1000};       // idle handles older than this are released (0 = keep until pressure)
   std::atomic<int64_t> async_unmap{0};           // unmap_from_kv_tensors only queues; a reclaimer thread does the driver calls
   std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
+  std::atomic<int64_t> hip_reg_group_mb{64};     // hybrid/drm: VA introduced to HIP per hipMemMap (0 = slot by slot)
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
@@ -140,10 +141,14 @@ struct KvRegion {
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
-  // hybrid backend: slots HIP has been told about (placeholder mapping made and removed again), and the placeholder
-  // handles (HIP handles, one per `fanout` slots so that HIP's per-handle bookkeeping stays small)
+  // hybrid/drm backends: slots HIP has been told about (placeholder mapping made and removed again). Registration
+  // happens in units of `reg_group` consecutive slots (64 MiB of VA per hipMemMap; the slots behind the last full
+  // group one by one), and the placeholder handles are HIP handles of the unit's size, one per 4096 units so that
+  // HIP's per-handle bookkeeping stays small.
   std::vector<uint8_t> registered;
-  std::vector<hipMemGenericAllocationHandle_t> shell;
+  size_t reg_group = 1;
+  std::vector<hipMemGenericAllocationHandle_t> shell, shell_group;
+  bool in_full_group(size_t slot) const { return reg_group > 1 && slot / reg_group < num_slots() / reg_group; }
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
                                        // 3 = released by the caller, physical unmap still queued (async unmap)
   size_t num_slots() const { return size / page_size; }
