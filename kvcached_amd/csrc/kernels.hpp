@@ -12,7 +12,7 @@ namespace kvc {
 // Bytes one workgroup zeroes / the alignment unit of zero_fill_pages.
 static constexpr size_t kFillSlabBytes = 64 * 1024;
 // Pointers (pages / regions) and moves one launch carries in its kernarg segment.
-static constexpr int kMaxPtrsPerLaunch = 256;
+static constexpr int kMaxPtrsPerLaunch = 1024; // 8 KiB of kernarg: a whole 1024-page batch is ONE launch (no drain/ramp between 4)
 static constexpr int kMaxRegionsPerLaunch = 128;
 static constexpr int kMaxMovesPerLaunch = 448; // 448 x 16 B + 128 x 8 B = 8 KiB of kernarg
 static constexpr int kMaxIdsPerLaunch = 1024; // block ids one index-kernel launch carries in its kernarg (8 KiB)

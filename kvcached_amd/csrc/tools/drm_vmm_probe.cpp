@@ -24,6 +24,8 @@
 #include <dirent.h>
 #include <fcntl.h>
 #include <limits.h>
+#include <sys/ioctl.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -120,15 +122,72 @@ static std::string render_node_for(const char *bdf) {
   return found;
 }
 
-static void tlb_shootdown() { // what the product does after a batch of (un)maps: a KFD free that the driver flushes for
-  void *p = nullptr;
-  CK(hipMalloc(&p, 2u << 20));
-  CK(hipFree(p));
+// KFD's gpu_id of the device at PCI domain:bus:dev.fn - /sys/class/kfd/kfd/topology/nodes/<n>/{gpu_id,properties}
+static uint32_t kfd_gpu_id_for(unsigned domain, unsigned bus, unsigned dev, unsigned fn) {
+  const unsigned want_loc = (bus << 8) | (dev << 3) | fn;
+  for (int n = 0; n < 64; n++) {
+    char path[256];
+    snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
+    FILE *f = fopen(path, "r");
+    if (!f) break;
+    unsigned long id = 0;
+    if (fscanf(f, "%lu", &id) != 1) id = 0;
+    fclose(f);
+    if (!id) continue; // a CPU node
+    snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+    f = fopen(path, "r");
+    if (!f) continue;
+    char key[64];
+    unsigned long long val;
+    unsigned long long loc = ~0ull, dom = 0;
+    while (fscanf(f, "%63s %llu", key, &val) == 2) {
+      if (!strcmp(key, "location_id")) loc = val;
+      if (!strcmp(key, "domain")) dom = val;
+    }
+    fclose(f);
+    if (loc == want_loc && dom == domain) return (uint32_t)id;
+  }
+  return 0;
+}
+
+
+// TLB invalidation. mode 0: what the product did first - hipMalloc + hipFree of 2 MiB (the KFD unmap inside hipFree
+// flushes). mode 1: the same flush with nothing around it - a small buffer of our own (allocated once on our own fd
+// of /dev/kfd, at a VA we reserved) is mapped to the GPU and unmapped again: AMDKFD_IOC_MAP_MEMORY_TO_GPU +
+// AMDKFD_IOC_UNMAP_MEMORY_FROM_GPU, the second of which ends in the heavyweight flush. mode 2: none (control: the
+// data check below must FAIL then, or it proves nothing).
+struct kfd_alloc_args {
+  uint64_t va_addr, size, handle, mmap_offset;
+  uint32_t gpu_id, flags;
+};
+struct kfd_map_args {
+  uint64_t handle, device_ids_array_ptr;
+  uint32_t n_devices, n_success;
+};
+#define KFD_ALLOC _IOWR('K', 0x16, kfd_alloc_args)
+#define KFD_MAP _IOWR('K', 0x18, kfd_map_args)
+#define KFD_UNMAP _IOWR('K', 0x19, kfd_map_args)
+static int g_mode = 0, g_kfd = -1;
+static uint32_t g_gpu_id = 0;
+static uint64_t g_flush_handle = 0;
+static void tlb_shootdown() {
+  if (g_mode == 2) return;
+  if (g_mode == 0) {
+    void *p = nullptr;
+    CK(hipMalloc(&p, 2u << 20));
+    CK(hipFree(p));
+    return;
+  }
+  kfd_map_args m{g_flush_handle, (uint64_t)(uintptr_t)&g_gpu_id, 1, 0};
+  if (syscall(SYS_ioctl, g_kfd, KFD_MAP, &m) != 0) { perror("KFD_MAP"); exit(1); }
+  m.n_success = 0;
+  if (syscall(SYS_ioctl, g_kfd, KFD_UNMAP, &m) != 0) { perror("KFD_UNMAP"); exit(1); }
 }
 
 int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1024;
   const int rounds = argc > 2 ? atoi(argv[2]) : 4;
+  g_mode = argc > 3 ? atoi(argv[3]) : 0;
   const size_t PAGE = 2u << 20;
   CK(hipSetDevice(0));
   CK(hipFree(nullptr));
@@ -162,6 +221,28 @@ int main(int argc, char **argv) {
   DK(amdgpu_device_initialize(fd, &maj, &min, &dev));
   printf("libdrm_amdgpu %u.%u: our fd %d, device's fd %d\n", maj, min, fd, amdgpu_device_get_fd(dev));
 
+  if (g_mode == 1) {
+    unsigned dom = 0, bus = 0, dv = 0, fn = 0;
+    sscanf(bdf, "%x:%x:%x.%x", &dom, &bus, &dv, &fn);
+    g_gpu_id = kfd_gpu_id_for(dom, bus, dv, fn);
+    g_kfd = open("/dev/kfd", O_RDWR | O_CLOEXEC);
+    void *fva = nullptr;
+    CK(hipMemAddressReserve(&fva, PAGE, PAGE, nullptr, 0)); // nothing else will ever use this VA
+    kfd_alloc_args a{};
+    a.va_addr = (uint64_t)fva;
+    a.size = 4096;
+    a.gpu_id = g_gpu_id;
+    a.flags = (1u << 31) | (1u << 28) | 1u; // VRAM | WRITABLE | NO_SUBSTITUTE
+    if (g_kfd < 0 || !g_gpu_id || syscall(SYS_ioctl, g_kfd, KFD_ALLOC, &a) != 0) return perror("flush buffer"), 6;
+    g_flush_handle = a.handle;
+    double t = now_us();
+    for (int i = 0; i < 200; i++) tlb_shootdown();
+    printf("KFD map+unmap of a 4 KiB buffer: %.1f us per pair\n", (now_us() - t) / 200);
+  } else if (g_mode == 0) {
+    double t = now_us();
+    for (int i = 0; i < 200; i++) tlb_shootdown();
+    printf("hipMalloc+hipFree of 2 MiB: %.1f us per pair\n", (now_us() - t) / 200);
+  }
   void *va0 = nullptr;
   CK(hipMemAddressReserve(&va0, (size_t)n * PAGE, PAGE, nullptr, 0));
   char *va = (char *)va0;

@@ -35,7 +35,8 @@ def _oracle_fill(lib, host: np.ndarray, offsets, page_bytes):
     (64 * KiB, 8, 1, 0),            # one slab
     (64 * KiB, 64, 17, 1),          # ragged selection of minimal pages
     (2 * MiB, 16, 5, 2),            # real page size, scattered
-    (2 * MiB, 300, 257, 3),         # more pages than one launch carries (256)
+    (2 * MiB, 300, 257, 3),         # a ragged count that is not a multiple of the 8-page XCD group
+    (64 * KiB, 2100, 1500, 6),      # more pages than one launch carries (1024)
     (6 * MiB, 6, 3, 4),             # page size that is not a power of two (3 x 2 MiB)
     (2 * MiB, 4, 0, 5),             # empty batch
 ])
@@ -78,7 +79,7 @@ def test_zero_fill_full_batch_properties(capi):
     capi.zero_fill_pages(ptrs, page)
     assert int(torch.count_nonzero(body)) == 0
     st = capi.get_stats()
-    assert st["fill_bytes"] == 2 * page * n and st["fill_launches"] == 2 * 4  # 1024 pages / 256 per launch
+    assert st["fill_bytes"] == 2 * page * n and st["fill_launches"] == 2      # 1024 pages = one launch each time
 
 
 def test_zero_fill_rejects_bad_arguments(capi):

@@ -11,19 +11,19 @@ ks, kt = newest("gpurun_out/prof_kt/runc/*_kernel_stats.csv"), newest("gpurun_ou
 shutil.copy(ks, f"profiles/{R}_rocprofv3_kernel_stats.csv")
 shutil.copy(newest("gpurun_out/prof_kt/runc/*_domain_stats.csv"), f"profiles/{R}_rocprofv3_domain_stats.csv")
 rows = list(csv.DictReader(open(kt)))
-big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] == "4194304"]
+big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] == "16777216"]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in big]
 w = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_w/runc/*_counter_collection.csv"))))
 rd = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_r/runc/*_counter_collection.csv"))))
-ws = [float(x["Counter_Value"]) for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] == "4194304"]
-fs = [float(x["Counter_Value"]) for x in rd if x["Counter_Name"] == "FETCH_SIZE" and x["Grid_Size"] == "4194304"]
+ws = [float(x["Counter_Value"]) for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] == "16777216"]
+fs = [float(x["Counter_Value"]) for x in rd if x["Counter_Name"] == "FETCH_SIZE" and x["Grid_Size"] == "16777216"]
 bench = json.loads(open("gpurun_out/bench.log").read().strip().splitlines()[-1])
 json.dump(bench, open(f"profiles/{R}_bench_n1.json", "w"))
 out = {"kernel": "kvc::zero_fill_pages_kernel<512,false,true>",
-       "launch_shape": "256 pages x 2 MiB = 8192 workgroups x 512 threads (grid 4194304)",
-       "algorithmic_bytes_per_launch": 536870912,
+       "launch_shape": "1024 pages x 2 MiB = 32768 workgroups x 512 threads (grid 16777216)",
+       "algorithmic_bytes_per_launch": 2147483648,
        "rocprofv3_kernel_trace": {"launches": len(d), "avg_us": round(sum(d) / len(d), 2), "median_us": round(statistics.median(d), 2),
-                                  "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(536870912 / (sum(d) / len(d)) / 1e3, 1)},
+                                  "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(2147483648 / (sum(d) / len(d)) / 1e3, 1)},
        "bench_hip_events": {"avg_launch_us": bench["roofline"]["avg_launch_us"], "achieved_GBps": bench["roofline"]["achieved"]},
        "pmc": {"WRITE_SIZE_KiB_per_launch": statistics.mean(ws), "FETCH_SIZE_KiB_per_launch_raw": round(statistics.mean(fs), 2),
                "note": "separate --pmc passes; WRITE_SIZE exact for 16 B/lane streaming stores; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B), MI355X_MICROARCH.md"},
