@@ -88,6 +88,24 @@ def test_argument_validation_matches_reference_messages():
         vmm_ops.kv_tensors_created()
 
 
+def test_backend_names_are_validated(monkeypatch):
+    """KVCACHED_VMM_BACKEND is read at init on every device; on "cpu" every valid name is accepted and has no effect
+    (no driver is touched), an unknown one is refused with the list."""
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setenv("KVCACHED_VMM_BACKEND", "cuda")
+    with pytest.raises(RuntimeError, match="'hip', 'hybrid', 'drm' or 'hsa'"):
+        vmm_ops.init_kvcached("cpu", 2 << 20, False)
+    for name in ("drm", "hybrid", "hip", "hsa"):
+        monkeypatch.setenv("KVCACHED_VMM_BACKEND", name)
+        vmm_ops.init_kvcached("cpu", 2 << 20, False)
+        try:
+            ts = vmm_ops.create_kv_tensors(4 << 20, 1, "cpu", 1)
+            assert vmm_ops.map_to_kv_tensors([0]) and vmm_ops.unmap_from_kv_tensors([0])
+            assert capi.get_option(110) == 0                     # pages straight from KFD: only ever on a GPU
+        finally:
+            vmm_ops.shutdown_kvcached()
+
+
 def test_page_allocator_surface_and_errors():
     from kvcached_amd import vmm_ops
     vmm_ops.init_kvcached("cpu", 2 << 20, False)
