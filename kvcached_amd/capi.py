@@ -25,6 +25,9 @@ KVC_E_NOT_CREATED = -7
 OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN, OPT_DEFER_UNMAP_SHOOTDOWN = 1, 2, 3, 4, 5, 6
 OPT_ASYNC_UNMAP = 7
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
+# read-only: the VMM backend in effect after init's self tests (0 hip, 1 hsa, 2 hybrid, 3 drm), and whether physical
+# pages come straight from KFD (drm backend only)
+OPT_EFFECTIVE_BACKEND, OPT_KFD_CREATE_ACTIVE = 108, 110
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _I64P = ctypes.POINTER(ctypes.c_int64)
