@@ -78,10 +78,13 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
  *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
  *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py).
- *   KVC_OPT_TLB_SHOOTDOWN  1 (default) = after every batch of VMM map/unmap calls force the driver to
- *                              invalidate the GPU TLBs before anything touches the affected VA. On
- *                              ROCm 7.2 / MI355X hipMemMap/hipMemUnmap alone leave stale translations
- *                              behind; 0 only for measurements.
+ *   KVC_OPT_TLB_SHOOTDOWN  1 (default) = force the driver to invalidate the GPU TLBs after every batch of unmaps, and
+ *                              after a batch of maps when a translation of the affected VA or pages can still be
+ *                              cached (zero alias replaced, deferred invalidation outstanding; a translation that
+ *                              was invalid is never cached on GFX9+, so mapping an unbacked slot needs none;
+ *                              KVCACHED_MAP_SHOOTDOWN=always invalidates after every map batch regardless). On
+ *                              ROCm 7.2 / MI355X the VMM calls alone leave stale translations behind
+ *                              (DESIGN.md §4.3); 0 only for measurements.
  *   KVC_OPT_DEFER_UNMAP_SHOOTDOWN 1 = the invalidation owed by an unmap batch whose pages all go back
  *                              to the library's own handle pool waits for the next map batch (which invalidates
  *                              before it touches anything) or for the moment handles are given back to the

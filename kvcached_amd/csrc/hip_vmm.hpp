@@ -599,9 +599,18 @@ inline bool vmm_try_set_access(void *va, size_t size, int dev) {
   const auto acc = make_rw_access(dev);
   return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
 }
+// Set by every unmap below, cleared by GpuContext::tlb_shootdown(): "a translation that was valid has been removed and
+// the GPU TLBs have not been invalidated since". While it is set, nothing may be mapped-and-touched, and no physical
+// page may go back to the driver, without an invalidation first: the VMM calls (HIP's, ROCr's and DRM's alike) leave
+// the old translation in the TLBs, and a later map at the same VA would be shadowed by it.
+inline std::atomic<bool> &tlb_stale() {
+  static std::atomic<bool> v{false};
+  return v;
+}
 // `h`: the handle mapped at `va`, when the caller knows it (needed to undo a direct DRM mapping; 0 = an alias or
 // a range, which are always ROCr's / HIP's).
 inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
+  tlb_stale().store(true);
   if (void *bo = h ? vmm_direct_bo(h) : nullptr) {
     const int r = DrmVm::instance().unmap(bo, va, size);
     if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA unmap failed: ") + strerror(r < 0 ? -r : r));
@@ -613,6 +622,7 @@ inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
     HIP_CHECK(hipMemUnmap(va, size));
 }
 inline bool vmm_try_unmap(void *va, size_t size, phys_handle_t h = 0) {
+  tlb_stale().store(true);
   if (void *bo = h ? vmm_direct_bo(h) : nullptr) return DrmVm::instance().unmap(bo, va, size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
   const bool ok = hipMemUnmap(va, size) == hipSuccess;

@@ -342,7 +342,7 @@ int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, 
 }
 
 void GpuContext::tlb_shootdown() {
-  tlb_owed_.store(false);
+  tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
   if (!options().tlb_shootdown.load()) return;
   const int64_t t0 = now_ns();
   void *p = nullptr;
@@ -421,6 +421,12 @@ bool hybrid_self_test(int dev) {
       (void)hipGetLastError();
       if (rocr_mapped) (void)hsa_amd_vmem_unmap(va, ps);
     }
+  }
+  { // the page was written through this VA: its translation must not outlive it (the page goes back below, and the
+    // VA may be handed out again for a region whose first map no longer invalidates by itself)
+    void *p = nullptr;
+    if (!env_bool("KVCACHED_TEST_SKIP_TEARDOWN_FLUSH", false) && hipMalloc(&p, kBasePage) == hipSuccess) (void)hipFree(p);
+    (void)hipGetLastError();
   }
   if (have_real) (void)hsa_amd_vmem_handle_release(real);
   if (shell) (void)hipMemRelease(shell);
@@ -603,6 +609,10 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   options().hip_reg_group_mb = std::max<int64_t>(0, env_i64("KVCACHED_HIP_REG_GROUP_MB", 64));
+  {
+    const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
+    options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
+  }
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
     const std::string b = be ? be : "drm";
@@ -861,6 +871,10 @@ void KvAllocator::backfill_all(KvRegion &r) {
     }
   } catch (...) {
     (void)vmm_try_unmap(r.base, r.size);
+    try {
+      ctx_->tlb_shootdown(); // the aliases were live translations
+    } catch (...) {
+    }
     for (size_t j = 0; j < made; ++j) (void)vmm_try_release(r.zero[j]);
     r.zero.clear();
     (void)hipGetLastError();
@@ -981,7 +995,11 @@ void KvAllocator::destroy_region(KvRegion &r) {
     r.mapped[i] = 0;
   }
   std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
-  if (ctx && !dead.empty()) { // this memory leaves the process: no translation to it may survive
+  if (r.backfilled && !whole) // aliases that could not be dropped in one call
+    for (size_t i = 0; i < r.num_slots(); ++i) (void)vmm_try_unmap(r.base + i * r.page_size, r.page_size);
+  // Pages and zero pages leave the process and the VA range may be handed out again: no translation of either may
+  // survive (any unmap above has set tlb_stale(); a region that never had anything mapped owes nothing).
+  if (ctx && tlb_stale().load() && !env_bool("KVCACHED_TEST_SKIP_TEARDOWN_FLUSH", false)) { // hook: prove the test has teeth
     try {
       ctx->tlb_shootdown();
     } catch (...) {
@@ -992,8 +1010,6 @@ void KvAllocator::destroy_region(KvRegion &r) {
     if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle during cleanup failed");
     stats().vmm.released++;
   }
-  if (r.backfilled && !whole) // aliases that could not be dropped in one call
-    for (size_t i = 0; i < r.num_slots(); ++i) (void)vmm_try_unmap(r.base + i * r.page_size, r.page_size);
   for (auto z : r.zero) (void)vmm_try_release(z);
   r.zero.clear();
   if (!vmm_try_address_free(r.base, r.size)) KVC_LOG(LOG_ERROR, "freeing the VA range of %s failed", r.name.c_str());
@@ -1218,7 +1234,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // Pages become usable in chunks: driver calls for <=`chunk` slots, ONE TLB shootdown (its cost grows only
   // mildly with the number of new mappings: 0.31 ms @256, 0.40 ms @1024), then the fill kernel
   // for exactly those slots runs on the GPU while the host issues the driver calls of the next chunk.
-  bool dirty_tlb = false; // driver calls issued since the last shootdown
+  // A TLB invalidation is owed before the new pages are touched only where a translation of these VAs (or of these
+  // pages) may still sit in a TLB: an unmap whose invalidation was deferred, a slot whose zero alias is being
+  // replaced, a page taken from a slot that was released but not yet unmapped. A translation that was INVALID is
+  // never cached on GFX9+ - KFD itself flushes after unmap only on this GPU family, and re-backing slots between busy
+  // neighbours with no invalidation after the map reads back right (tools/drm_vmm_probe.cpp mode 3) - so a plain
+  // map of an unbacked slot whose last unmap was invalidated needs nothing (KVCACHED_MAP_SHOOTDOWN=always restores it).
+  const bool always_flush = options().map_shootdown_always.load() != 0;
+  bool dirty_tlb = ctx->tlb_owed(); // an invalidation is owed before anything of this batch is touched
   const size_t chunk = (size_t)std::max<int64_t>(1, options().fill_chunk_slots.load());
   auto launch_pending = [&](bool all) {
     size_t i = 0;
@@ -1239,7 +1262,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     const int64_t ta = now_ns();
     vmm_set_access(run_start, run_len, ctx->dev());
     stats().t_access += now_ns() - ta;
-    dirty_tlb = true;
+    if (always_flush) dirty_tlb = true;
     if (fill) {
       pending.insert(pending.end(), run_pages.begin(), run_pages.end());
       launch_pending(false);
@@ -1268,7 +1291,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
       if (vmm_hip_registered() && !r.registered[s.index]) register_slot(r, s.index); // once per slot
-      if (r.backfilled) vmm_unmap(va, ps);
+      if (r.backfilled) {
+        vmm_unmap(va, ps);
+        dirty_tlb = true; // the alias's translation is live
+      }
       int64_t t1 = now_ns();
       bool recycled = false;
       Phys ph;
@@ -1301,7 +1327,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       r.mapped[s.index] = imported ? 2 : 1;
       done.push_back(s);
       if (!needs_access) { // mapped readable+writable in one ioctl (drm backend): straight to the fill queue
-        dirty_tlb = true;
+        if (always_flush) dirty_tlb = true;
         if (fill) {
           pending.push_back(va);
           launch_pending(false);

@@ -33,6 +33,7 @@ struct Options {
   std::atomic<int64_t> async_unmap{0};           // unmap_from_kv_tensors only queues; a reclaimer thread does the driver calls
   std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
   std::atomic<int64_t> hip_reg_group_mb{64};     // hybrid/drm: VA introduced to HIP per hipMemMap (0 = slot by slot)
+  std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
@@ -97,9 +98,10 @@ public:
   // the KFD map ioctl behind an ordinary >= 2 MiB hipMalloc does.
   void tlb_shootdown();
   // unmap path: the invalidation is owed but nothing needs it yet (see KvAllocator::unmap_slots)
-  void defer_tlb_shootdown() { tlb_owed_.store(true); }
+  void defer_tlb_shootdown() { tlb_stale().store(true); }
+  bool tlb_owed() const { return tlb_stale().load(); } // some unmap since the last invalidation (hip_vmm.hpp)
   void flush_deferred_shootdown() {
-    if (tlb_owed_.load()) tlb_shootdown();
+    if (tlb_stale().load()) tlb_shootdown();
   }
 
 private:
@@ -112,7 +114,6 @@ private:
   void harvest();
   int dev_;
   hipStream_t stream_ = nullptr;
-  std::atomic<bool> tlb_owed_{false};
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];

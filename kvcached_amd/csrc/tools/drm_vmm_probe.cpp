@@ -170,12 +170,15 @@ struct kfd_map_args {
 static int g_mode = 0, g_kfd = -1;
 static uint32_t g_gpu_id = 0;
 static uint64_t g_flush_handle = 0;
+static void tlb_flush_now() {
+  void *p = nullptr;
+  CK(hipMalloc(&p, 2u << 20));
+  CK(hipFree(p));
+}
 static void tlb_shootdown() {
   if (g_mode == 2) return;
-  if (g_mode == 0) {
-    void *p = nullptr;
-    CK(hipMalloc(&p, 2u << 20));
-    CK(hipFree(p));
+  if (g_mode == 0 || g_mode == 3) {
+    tlb_flush_now();
     return;
   }
   kfd_map_args m{g_flush_handle, (uint64_t)(uintptr_t)&g_gpu_id, 1, 0};
@@ -288,6 +291,65 @@ int main(int argc, char **argv) {
   hipStream_t s;
   CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   std::vector<unsigned> host_tags(n);
+  if (g_mode == 3) {
+    // Is the invalidation after a MAP needed at all? KFD itself does not flush when it maps on this GPU family (it
+    // flushes after unmap only): a translation that was invalid cannot sit in a TLB on GFX9+. Adversarial version:
+    // even slots stay mapped and are read by a kernel while the odd slots are unmapped (so the page-table lines that
+    // hold the odd slots' invalid entries are fetched again and again), then the odd slots are re-backed with
+    // permuted pages and checked IMMEDIATELY, with no invalidation since the one that followed their unmap.
+    const int half = n / 2;
+    auto odd_handle = [&](int j, int rd) { return 2 * (int)(((long)j * 37 + rd * 101) % half) + 1; }; // handle of odd slot 2j+1
+    for (int i = 0; i < n; i++) DK(amdgpu_bo_va_op(bo[i], 0, PAGE, (uint64_t)(va + (size_t)i * PAGE), 0, AMDGPU_VA_OP_MAP));
+    tlb_flush_now();
+    for (int i = 0; i < n; i++) host_tags[i] = 0x70000000u | (unsigned)i; // page i carries its handle number
+    CK(hipMemcpyAsync(tags, host_tags.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    stamp_pages<<<dim3(8, n), 256, 0, s>>>((unsigned *)va, PAGE / 4, tags);
+    CK(hipStreamSynchronize(s));
+    std::vector<int> cur(half); // handle currently behind odd slot 2j+1
+    for (int j = 0; j < half; j++) cur[j] = 2 * j + 1;
+    for (int round = 1; round <= rounds; round++) {
+      for (int j = 0; j < half; j++) DK(amdgpu_bo_va_op(bo[cur[j]], 0, PAGE, (uint64_t)(va + (size_t)(2 * j + 1) * PAGE), 0, AMDGPU_VA_OP_UNMAP));
+      tlb_flush_now(); // the one invalidation of the cycle
+      // neighbours at work while the odd slots are unbacked
+      unsigned long long bad_even = 0, bad_odd = 0;
+      CK(hipMemsetAsync(cnt, 0, 8, s));
+      for (int rep = 0; rep < 3; rep++)
+        for (int j = 0; j < half; j++) check_pages<<<dim3(8, 1), 256, 0, s>>>((const unsigned *)(va + (size_t)(2 * j) * PAGE), PAGE / 4, tags + 2 * j, cnt);
+      CK(hipMemcpyAsync(&bad_even, cnt, 8, hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      double a = now_us();
+      for (int j = 0; j < half; j++) {
+        cur[j] = odd_handle(j, round);
+        DK(amdgpu_bo_va_op(bo[cur[j]], 0, PAGE, (uint64_t)(va + (size_t)(2 * j + 1) * PAGE), 0, AMDGPU_VA_OP_MAP));
+      }
+      double b = now_us();
+      // no invalidation here: every odd slot must show the page that was just put behind it
+      std::vector<unsigned> want(half);
+      for (int j = 0; j < half; j++) want[j] = 0x70000000u | (unsigned)cur[j];
+      unsigned *wt;
+      CK(hipMalloc(&wt, half * sizeof(unsigned)));
+      CK(hipMemcpyAsync(wt, want.data(), half * sizeof(unsigned), hipMemcpyHostToDevice, s));
+      CK(hipMemsetAsync(cnt, 0, 8, s));
+      for (int j = 0; j < half; j++) check_pages<<<dim3(8, 1), 256, 0, s>>>((const unsigned *)(va + (size_t)(2 * j + 1) * PAGE), PAGE / 4, wt + j, cnt);
+      CK(hipMemcpyAsync(&bad_odd, cnt, 8, hipMemcpyDeviceToHost, s));
+      CK(hipStreamSynchronize(s));
+      CK(hipFree(wt)); // (a small block: served from the runtime's cache, no driver trip)
+      printf("round %d: odd slots re-backed (map %.2f us/page) and read with NO invalidation after the map: wrong words %llu (even neighbours: %llu)\n",
+             round, (b - a) / half, bad_odd, bad_even);
+      fflush(stdout);
+    }
+    for (int i = 0; i < n; i++) {
+      const int hnd = (i & 1) ? cur[i / 2] : i;
+      DK(amdgpu_bo_va_op(bo[hnd], 0, PAGE, (uint64_t)(va + (size_t)i * PAGE), 0, AMDGPU_VA_OP_UNMAP));
+    }
+    tlb_flush_now();
+    for (int i = 0; i < n; i++) {
+      DK(amdgpu_bo_free(bo[i]));
+      HK(hsa_amd_vmem_handle_release(h[i]));
+    }
+    printf("done\n");
+    return 0;
+  }
   for (int round = 0; round < rounds; round++) {
     auto handle_at = [&](int i, int rd) { return (int)(((long)i * 37 + rd * 101) % n); }; // 37 coprime with 1024
     double a = now_us();

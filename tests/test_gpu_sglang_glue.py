@@ -63,12 +63,21 @@ def test_alloc_extend_indices(gpu_lib, cfg):
 
 
 def test_alloc_extend_accepts_int32_lengths(gpu_lib):
+    """SGLang hands int32 lengths on some paths: converted on the caller's stream, same results. Many small seeded
+    batches back to back (nothing synchronises in between: the temporaries of one call are recycled by the next)."""
     from kvcached_amd.integration.sglang.allocators import alloc_extend_indices
-    case = G.extend_case(seed=21, bs=9, tpb=16, max_prefix=50, max_extend=50)
-    want = O.alloc_extend(case["prefix_lens"], case["seq_lens"], case["last_loc"], case["free_pages"], 16)
-    got = alloc_extend_indices(dev(case["prefix_lens"]).to(torch.int32), dev(case["seq_lens"]).to(torch.int32),
-                               dev(case["last_loc"]), [int(x) for x in case["free_pages"]], 16, case["extend_num_tokens"])
-    assert np.array_equal(got.cpu().numpy(), want)
+    pending = []
+    for seed in range(21, 61):
+        case = G.extend_case(seed=seed, bs=1 + seed % 13, tpb=16, max_prefix=50, max_extend=50 + 20 * (seed % 5))
+        want = O.alloc_extend(case["prefix_lens"], case["seq_lens"], case["last_loc"], case["free_pages"], 16)
+        got = alloc_extend_indices(dev(case["prefix_lens"]).to(torch.int32), dev(case["seq_lens"]).to(torch.int32),
+                                   dev(case["last_loc"]), [int(x) for x in case["free_pages"]], 16, case["extend_num_tokens"])
+        pending.append((seed, got, want))
+    torch.cuda.synchronize()
+    for seed, got, want in pending:
+        got = got.cpu().numpy()
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, (seed, bad[:8].tolist(), got[bad[:8]].tolist(), want[bad[:8]].tolist(), len(want))
 
 
 DECODE_GPU_CASES = G.DECODE_CASES + [

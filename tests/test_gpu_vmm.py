@@ -133,7 +133,8 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     """KVC_OPT_DEFER_UNMAP_SHOOTDOWN in lazy mode: an unmap batch whose handles all return to the pool performs no
     TLB invalidation of its own; the next map batch invalidates before anything touches
     the recycled pages, and handles that leave the pool for the driver are preceded by one. Whatever the slot a
-    recycled (dirty) handle lands on, reads see zeros first and every page stays private."""
+    recycled (dirty) handle lands on, reads see zeros first and every page stays private. A map batch with nothing
+    owed (the very first one here) invalidates nothing: a translation that was invalid is never cached."""
     ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=False, kv=1, unified=True)
     assert capi.get_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN) == 0          # off by default
     capi.set_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN, 1)
@@ -143,11 +144,13 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     rng = random.Random(0)
     live = {}
     capi.reset_stats()
+    owed = False
     for r in range(8):
         slots = rng.sample([s for s in range(32) if s not in live], rng.randint(3, 8))   # recycled handles, new slots
         n0 = capi.get_stats()["tlb_shootdowns"]
         assert ops.map_to_kv_tensors([s * PAGE for s in slots])
-        assert capi.get_stats()["tlb_shootdowns"] == n0 + 1
+        assert capi.get_stats()["tlb_shootdowns"] == n0 + int(owed)
+        owed = False
         for s in slots:
             page = t[s * epp:(s + 1) * epp]
             assert int(torch.count_nonzero(page)) == 0, (r, s)          # recycled handles were dirty
@@ -160,6 +163,7 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
         n1 = capi.get_stats()["tlb_shootdowns"]
         assert ops.unmap_from_kv_tensors([s * PAGE for s in victims])
         assert capi.get_stats()["tlb_shootdowns"] == n1                  # deferred
+        owed = True
         for s in victims:
             live.pop(s)
     # the pool shrinks to nothing: the owed invalidation happens before the first handle goes to the driver
@@ -176,6 +180,76 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     n = capi.get_stats()["tlb_shootdowns"]
     assert ops.unmap_from_kv_tensors([5 * PAGE])
     assert capi.get_stats()["tlb_shootdowns"] == n + 1
+
+
+def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, monkeypatch):
+    """Unmaps invalidate the TLBs (the VMM calls do not); maps need to only where something valid may still be cached:
+    a zero alias being replaced (compat mode) or an invalidation somebody deferred. Mapping an unbacked slot whose
+    last unmap was invalidated needs nothing - an invalid translation is never cached on GFX9+ (KFD itself flushes
+    after unmap only on this GPU family; tools/drm_vmm_probe.cpp mode 3). Data check: pages recycled through the
+    pool land on other slots between live neighbours and read zeros, neighbours keep their contents."""
+    epp = PAGE // 2
+    for mode, per_map in (("lazy", 0), ("compat", 1), ("always", 1)):
+        if mode == "always":
+            monkeypatch.setenv("KVCACHED_MAP_SHOOTDOWN", "always")
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=(mode == "compat"), kv=1, unified=True)
+        t = ts[0]
+        capi.reset_stats()
+        even = [s * PAGE for s in range(0, 32, 2)]
+        assert ops.map_to_kv_tensors(even)
+        assert capi.get_stats()["tlb_shootdowns"] == per_map, mode
+        for s in range(0, 32, 2):
+            t[s * epp:(s + 1) * epp].fill_(s + 1)
+        for r in range(4):
+            odd = [s * PAGE for s in range(1, 32, 2)]
+            n0 = capi.get_stats()["tlb_shootdowns"]
+            assert ops.map_to_kv_tensors(odd[r:] + odd[:r])                # recycled pages, rotated over the slots
+            assert capi.get_stats()["tlb_shootdowns"] == n0 + per_map, (mode, r)
+            for s in range(1, 32, 2):
+                assert int(torch.count_nonzero(t[s * epp:(s + 1) * epp])) == 0, (mode, r, s)
+                t[s * epp:(s + 1) * epp].fill_(1000 * (r + 1) + s)
+            torch.cuda.synchronize()
+            for s in range(0, 32, 2):
+                assert bool((t[s * epp:(s + 1) * epp] == s + 1).all()), (mode, r, s)
+            n1 = capi.get_stats()["tlb_shootdowns"]
+            assert ops.unmap_from_kv_tensors(odd)
+            assert capi.get_stats()["tlb_shootdowns"] == n1 + 1, (mode, r)   # every unmap batch invalidates
+        assert ops.unmap_from_kv_tensors(even)
+        ops.shutdown_kvcached()
+
+
+def test_reinit_never_writes_through_a_translation_of_a_previous_life(vmm):
+    """Map batches no longer invalidate by themselves, so every path that removes a LIVE translation must: region
+    teardown (pages and zero aliases), the init self tests, rollbacks. Otherwise: a region is torn down, its physical
+    pages go back to the driver and are handed to somebody else (here: torch canaries), the next init reserves the
+    same VA, and the zero fill of its first map batch lands - through the stale translation - in the canaries."""
+    epp = PAGE // 2
+    canaries = []
+    n_pages = 96
+    for life in range(6):
+        backfill = life % 2 == 1
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=n_pages * PAGE, backfill=backfill, kv=1, unified=True)
+        offs = [i * PAGE for i in range(n_pages) if (i * 7 + life) % 3]
+        assert ops.map_to_kv_tensors(offs)                           # zero fill of (probably) the same VAs as last life
+        for c, want in canaries:
+            assert bool((c == want).all()), f"life {life}: a canary that owns recycled physical pages was overwritten"
+        t = ts[0]
+        for o in offs:
+            i = o // PAGE
+            assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0
+            t[i * epp:(i + 1) * epp].fill_(life + 1)                    # make the pages dirty and their translations hot
+        torch.cuda.synchronize()
+        if life % 3 == 0:
+            assert ops.unmap_from_kv_tensors(offs[::2])                # some go through the pool, the rest die mapped
+        ops.shutdown_kvcached()
+        # whoever gets those physical pages next. No canary is ever freed and the cache is never emptied: a hipFree
+        # that reaches the driver invalidates the TLBs on its own and would hide a missing invalidation of ours.
+        for k in range(3):
+            c = torch.full((n_pages * PAGE // 8,), 0x5A5A0000 + life * 16 + k, dtype=torch.int32, device=DEV)
+            canaries.append((c, 0x5A5A0000 + life * 16 + k))
+        torch.cuda.synchronize()
+    for c, want in canaries:
+        assert bool((c == want).all())
 
 
 def test_async_unmap_queue_reclaimer_and_rebacking(vmm):
