@@ -1242,11 +1242,19 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // map of an unbacked slot whose last unmap was invalidated needs nothing (KVCACHED_MAP_SHOOTDOWN=always restores it).
   const bool always_flush = options().map_shootdown_always.load() != 0;
   bool dirty_tlb = ctx->tlb_owed(); // an invalidation is owed before anything of this batch is touched
+  // Fill launches: the kernel for the slots mapped so far runs while the host issues the driver calls for the rest, so
+  // only the LAST launch is exposed. Large launches are more efficient (ramp and tail are ~10 us whatever the size:
+  // 6.8 TB/s at 2 GiB, 6.4 at 512 MiB), the exposed one should be short: a batch of n >= 512 slots is filled as
+  // 3/4 + 1/4 (1024 pages: 768 pages hidden behind the last 256 maps, 256 pages = 0.09 ms exposed instead of 0.33 ms
+  // for one launch; p50 map batch 2.85 -> 2.6 ms). KVCACHED_FILL_CHUNK_SLOTS caps a launch (and while a TLB
+  // invalidation is owed per chunk - compat mode, deferred unmaps - larger chunks mean fewer of them).
   const size_t chunk = (size_t)std::max<int64_t>(1, options().fill_chunk_slots.load());
+  const size_t n_total = slots.size();
+  size_t next_cut = n_total >= 512 ? std::min(chunk, n_total - std::max<size_t>(128, n_total / 4)) : chunk;
   auto launch_pending = [&](bool all) {
     size_t i = 0;
-    while (pending.size() - i >= chunk || (all && i < pending.size())) {
-      const size_t end = i + std::min(chunk, pending.size() - i);
+    while (pending.size() - i >= next_cut || (all && i < pending.size())) {
+      const size_t end = i + std::min(next_cut, pending.size() - i);
       if (dirty_tlb) {
         ctx->tlb_shootdown();
         dirty_tlb = false;
@@ -1254,6 +1262,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       for (; i < end; i += std::min<size_t>(kMaxPtrsPerLaunch, end - i))
         ctx->zero_fill(pending.data() + i, std::min<size_t>(kMaxPtrsPerLaunch, end - i), ps, nullptr);
       launched = true;
+      next_cut = chunk; // after the first launch: whatever is left, in launches of at most `chunk`
     }
     pending.erase(pending.begin(), pending.begin() + i);
   };

@@ -11,21 +11,31 @@ ks, kt = newest("gpurun_out/prof_kt/runc/*_kernel_stats.csv"), newest("gpurun_ou
 shutil.copy(ks, f"profiles/{R}_rocprofv3_kernel_stats.csv")
 shutil.copy(newest("gpurun_out/prof_kt/runc/*_domain_stats.csv"), f"profiles/{R}_rocprofv3_domain_stats.csv")
 rows = list(csv.DictReader(open(kt)))
-big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] == "16777216"]
+# the bench's fill launches: a 1024-page batch is filled as 768 + 256 pages (grid = pages x 32 workgroups x 512 threads)
+SHAPES = {"12582912": 768, "4194304": 256, "16777216": 1024}
+big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] in SHAPES]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in big]
+algo = [SHAPES[r["Grid_Size_X"]] * 2097152 for r in big]
 w = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_w/runc/*_counter_collection.csv"))))
 rd = list(csv.DictReader(open(newest("gpurun_out/prof_pmc_r/runc/*_counter_collection.csv"))))
-ws = [float(x["Counter_Value"]) for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] == "16777216"]
-fs = [float(x["Counter_Value"]) for x in rd if x["Counter_Name"] == "FETCH_SIZE" and x["Grid_Size"] == "16777216"]
+ws = [float(x["Counter_Value"]) for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] in SHAPES and "zero_fill" in x["Kernel_Name"]]
+fs = [float(x["Counter_Value"]) for x in rd if x["Counter_Name"] == "FETCH_SIZE" and x["Grid_Size"] in SHAPES and "zero_fill" in x["Kernel_Name"]]
+wa = [SHAPES[x["Grid_Size"]] * 2097152 for x in w if x["Counter_Name"] == "WRITE_SIZE" and x["Grid_Size"] in SHAPES and "zero_fill" in x["Kernel_Name"]]
 bench = json.loads(open("gpurun_out/bench.log").read().strip().splitlines()[-1])
 json.dump(bench, open(f"profiles/{R}_bench_n1.json", "w"))
+per_shape = {}
+for r, us in zip(big, d):
+    per_shape.setdefault(SHAPES[r["Grid_Size_X"]], []).append(us)
 out = {"kernel": "kvc::zero_fill_pages_kernel<512,false,true>",
-       "launch_shape": "1024 pages x 2 MiB = 32768 workgroups x 512 threads (grid 16777216)",
-       "algorithmic_bytes_per_launch": 2147483648,
+       "launch_shape": "a 1024-page batch = one launch of 768 pages (hidden behind the last 256 maps) + one of 256; 32 workgroups x 512 threads per 2 MiB page",
+       "algorithmic_bytes_per_launch": int(sum(algo) / len(algo)),
        "rocprofv3_kernel_trace": {"launches": len(d), "avg_us": round(sum(d) / len(d), 2), "median_us": round(statistics.median(d), 2),
-                                  "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(2147483648 / (sum(d) / len(d)) / 1e3, 1)},
+                                  "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(sum(algo) / sum(d) / 1e3, 1),
+                                  "per_shape": {f"{k}_pages": {"launches": len(v), "avg_us": round(sum(v) / len(v), 2),
+                                                               "GBps": round(k * 2097152 / (sum(v) / len(v)) / 1e3, 1)} for k, v in sorted(per_shape.items())}},
        "bench_hip_events": {"avg_launch_us": bench["roofline"]["avg_launch_us"], "achieved_GBps": bench["roofline"]["achieved"]},
        "pmc": {"WRITE_SIZE_KiB_per_launch": statistics.mean(ws), "FETCH_SIZE_KiB_per_launch_raw": round(statistics.mean(fs), 2),
+               "WRITE_SIZE_over_algorithmic": round(sum(ws) * 1024 / sum(wa), 6),
                "note": "separate --pmc passes; WRITE_SIZE exact for 16 B/lane streaming stores; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B), MI355X_MICROARCH.md"},
        "write_bytes_per_launch": int(statistics.mean(ws) * 1024), "read_bytes_per_launch": int(2 * statistics.mean(fs) * 1024)}
 out["hbm_bytes_per_launch"] = out["write_bytes_per_launch"] + out["read_bytes_per_launch"]
