@@ -1193,9 +1193,10 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
   return false;
 }
 
-// The hot loop. Per slot: [unmap the zero alias] -> pooled handle -> hipMemMap; per contiguous run: one
-// hipMemSetAccess; per chunk (KVCACHED_FILL_CHUNK_SLOTS, 1024): zero_fill_pages launches (<=256 pages each) that run on the GPU while
-// the host keeps issuing driver calls for the next slots; one stream sync at the end.
+// The hot loop. Per slot: [register with HIP, once per 64 MiB group] -> [unmap the zero alias] -> pooled handle -> map
+// (drm backend: one GEM_VA ioctl; else map + one set_access per contiguous run); zero_fill_pages launches that run on
+// the GPU while the host keeps issuing driver calls for the next slots (3/4 of the batch, then the rest); a TLB
+// invalidation before the first fill only if one is owed; one stream sync at the end.
 void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported) {
   if (slots.empty()) return;
   if (!dev_.is_gpu) { // reference CPUPage::map is a no-op (page.cpp:34-37); keep the double-map diagnostics
