@@ -159,6 +159,7 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
             if not burst:
                 unmapper(offs)
                 per_unmap.append(time.perf_counter() - tb)
+        capi.flush_unmaps()   # nothing of the timed work is left owed or in flight on the library's own thread
         if sync:
             sync()
         if barrier:
@@ -447,6 +448,7 @@ def main():
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
+                        ("unmap_waits_for_its_own_tlb_invalidation", "lazy", None, 0, False, True),
                         ("hybrid_backend_same_cycle", "lazy", None, 0, False, True),
                         ("hip_backend_same_cycle", "lazy", None, 0, False, True),
                         ("hip_backend_compat_zero_backfill_sharded", "compat", None, 0, False, True),
@@ -459,7 +461,9 @@ def main():
                         ("page_size_8MiB_instead_of_2MiB", "lazy", None, 0, False, True),
                         ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
                     try:
-                        nsteps = 24 if (burst or name.startswith("fresh_va") or name.endswith("_backend_same_cycle")) else 8
+                        if name.startswith("unmap_waits"):
+                            os.environ["KVCACHED_ASYNC_SHOOTDOWN"] = "false"
+                        nsteps = 24 if (burst or name.startswith(("fresh_va", "unmap_waits")) or name.endswith("_backend_same_cycle")) else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
                                      backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
                                      else ("hip" if name.startswith("hip_") else ("hybrid" if name.startswith("hybrid_") else args.backend)),
@@ -473,6 +477,8 @@ def main():
                         variants[name]["fill_GBps"] = rf["achieved"] if rf else None
                     except Exception as e:
                         variants[name] = {"error": str(e)[:200]}
+                    finally:
+                        os.environ.pop("KVCACHED_ASYNC_SHOOTDOWN", None)
                 line["variants"] = variants
                 try:
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)

@@ -28,6 +28,7 @@ OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 # read-only: the VMM backend in effect after init's self tests (0 hip, 1 hsa, 2 hybrid, 3 drm), and whether physical
 # pages come straight from KFD (drm backend only)
 OPT_EFFECTIVE_BACKEND, OPT_KFD_CREATE_ACTIVE = 108, 110
+OPT_BACKGROUND_SHOOTDOWNS = 111  # read-only: TLB invalidations performed by the library's own threads so far
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _I64P = ctypes.POINTER(ctypes.c_int64)

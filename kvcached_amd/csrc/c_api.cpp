@@ -150,6 +150,7 @@ int64_t kvc_get_option(int opt) {
   case 107: return options().pool_idle_ms;
   case 109: return options().async_shootdown;
   case 108: return vmm_backend().load(); // effective VMM backend: 0 hip, 1 hsa, 2 hybrid, 3 drm (read-only)
+  case 111: return background_shootdowns().load(); // TLB invalidations done by the library's own threads (read-only)
   case 110: return vmm_backend().load() == kVmmDrm && DrmVm::instance().kfd_ready() ? 1 : 0; // physical pages straight from KFD (read-only)
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;

@@ -61,6 +61,14 @@ GpuContext *context_for(int dev) {
 } // namespace
 
 // ------------------------------------------------------------------ GpuContext
+namespace {
+thread_local bool tl_background_thread = false; // set in the flusher / housekeeping threads
+}
+std::atomic<int64_t> &background_shootdowns() {
+  static std::atomic<int64_t> v{0};
+  return v;
+}
+
 GpuContext::GpuContext(int dev) : dev_(dev) {
   HIP_CHECK(hipSetDevice(dev_));
   int supports_vmm = 0;
@@ -78,6 +86,12 @@ GpuContext::GpuContext(int dev) : dev_(dev) {
 }
 
 GpuContext::~GpuContext() {
+  {
+    std::lock_guard<std::mutex> g(fl_mu_);
+    fl_stop_ = true;
+  }
+  fl_cv_.notify_all();
+  if (flusher_.joinable()) flusher_.join();
   (void)hipSetDevice(dev_);
   for (auto &t : inflight_) {
     (void)hipEventDestroy(t.a);
@@ -151,6 +165,7 @@ void GpuContext::housekeeping() {
   }
   if (ps.empty()) return;
   (void)hipSetDevice(dev_);
+  tl_background_thread = true; // the allocator's watcher thread
   try {
     flush_deferred_shootdown(); // the invalidation unmap batches left to this thread (KVCACHED_ASYNC_SHOOTDOWN)
   } catch (const std::exception &e) {
@@ -341,6 +356,41 @@ int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, 
   return count;
 }
 
+void GpuContext::ensure_flushed() {
+  std::lock_guard<std::mutex> g(flush_mu_);
+  if (tlb_stale().load()) tlb_shootdown();
+}
+
+void GpuContext::request_async_flush() {
+  {
+    std::lock_guard<std::mutex> g(fl_mu_);
+    if (fl_stop_) return;
+    if (!flusher_.joinable()) flusher_ = std::thread([this] { flusher_loop(); });
+    fl_kick_ = true;
+  }
+  fl_cv_.notify_one();
+}
+
+void GpuContext::flusher_loop() {
+  (void)hipSetDevice(dev_);
+  tl_background_thread = true;
+  std::unique_lock<std::mutex> lk(fl_mu_);
+  while (!fl_stop_) {
+    fl_cv_.wait(lk, [&] { return fl_stop_ || fl_kick_; });
+    if (fl_stop_) break;
+    fl_kick_ = false;
+    lk.unlock();
+    try {
+      ensure_flushed();
+    } catch (const std::exception &e) {
+      KVC_LOG(LOG_ERROR, "background TLB invalidation failed: %s", e.what());
+      (void)hipGetLastError();
+    }
+    lk.lock();
+  }
+}
+
+// Callers either hold flush_mu_ (ensure_flushed) or want an unconditional invalidation of their own.
 void GpuContext::tlb_shootdown() {
   tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
   if (!options().tlb_shootdown.load()) return;
@@ -361,6 +411,7 @@ void GpuContext::tlb_shootdown() {
     HIP_CHECK(hipFree(p));
   }
   stats().tlb_shootdowns++;
+  if (tl_background_thread) background_shootdowns()++;
   stats().shootdown_ns += now_ns() - t0;
 }
 
@@ -819,6 +870,10 @@ void KvAllocator::flush_all_unmaps() {
     for (auto &kv : g_allocators) all.push_back(kv.second.get());
   }
   for (auto *a : all) a->flush_unmaps();
+  if (GpuContext *ctx = gpu()) { // ... and no invalidation is left owed or in flight
+    ctx->bind();
+    ctx->ensure_flushed();
+  }
 }
 
 size_t KvAllocator::pending_unmap_bytes() { return g_pending_unmap_bytes.load(); }
@@ -1256,10 +1311,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     size_t i = 0;
     while (pending.size() - i >= next_cut || (all && i < pending.size())) {
       const size_t end = i + std::min(next_cut, pending.size() - i);
-      if (dirty_tlb) {
-        ctx->tlb_shootdown();
-        dirty_tlb = false;
-      }
+      if (always_flush && dirty_tlb) tlb_stale().store(true);
+      dirty_tlb = false;
+      ctx->ensure_flushed(); // only if an unmap (ours in this batch, or an earlier one still owed) has happened since the last one
       for (; i < end; i += std::min<size_t>(kMaxPtrsPerLaunch, end - i))
         ctx->zero_fill(pending.data() + i, std::min<size_t>(kMaxPtrsPerLaunch, end - i), ps, nullptr);
       launched = true;
@@ -1353,7 +1407,8 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     }
     flush_run();
     if (fill) launch_pending(true);
-    if (dirty_tlb) ctx->tlb_shootdown(); // nothing may reach the new pages through a stale translation
+    if (always_flush && dirty_tlb) tlb_stale().store(true);
+    ctx->ensure_flushed(); // nothing may reach the new pages through a stale translation
     const int64_t ts = now_ns();
     if (launched) ctx->sync(nullptr);
     stats().t_sync += now_ns() - ts;
@@ -1470,11 +1525,13 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   //     is left to its next 100 ms tick (GpuContext::housekeeping) - the 0.3-0.4 ms KFD round trip leaves the
   //     caller's free() and, unless an alloc follows within that tick, reaches nobody's critical path
   //     (KVCACHED_ASYNC_SHOOTDOWN, on by default; one page id: free() 0.6 -> 0.2 ms).
-  const bool defer = options().defer_unmap_shootdown.load() || (options().async_shootdown.load() && ctx->has_housekeeper());
+  const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
   if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer)
-    ctx->tlb_shootdown();
+    ctx->ensure_flushed();
+  else if (options().defer_unmap_shootdown.load())
+    ctx->defer_tlb_shootdown(); // explicitly left to the next map batch / release to the driver
   else
-    ctx->defer_tlb_shootdown();
+    ctx->request_async_flush(); // this context's own thread does it now, off the caller's path
   for (auto h : u.imported) {
     if (!vmm_try_release(h)) KVC_LOG(LOG_ERROR, "releasing an imported handle failed");
   }

@@ -59,6 +59,7 @@ struct Stats {
   void reset();
 };
 Stats &stats();
+std::atomic<int64_t> &background_shootdowns(); // TLB invalidations performed off the callers' threads (option 111)
 
 // Per-device state: stream for our kernels, event pool for per-launch timing, handle pools.
 class GpuContext {
@@ -100,9 +101,14 @@ public:
   // unmap path: the invalidation is owed but nothing needs it yet (see KvAllocator::unmap_slots)
   void defer_tlb_shootdown() { tlb_stale().store(true); }
   bool tlb_owed() const { return tlb_stale().load(); } // some unmap since the last invalidation (hip_vmm.hpp)
-  void flush_deferred_shootdown() {
-    if (tlb_stale().load()) tlb_shootdown();
-  }
+  // Invalidate if (and only if) an unmap has happened since the last invalidation; a caller that arrives while
+  // another thread's invalidation is in flight waits for it instead of issuing a second one.
+  void ensure_flushed();
+  void flush_deferred_shootdown() { ensure_flushed(); }
+  // Have this context's own thread do ensure_flushed() right away (started on first use): the unmap path's 0.3-0.5 ms
+  // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
+  // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
+  void request_async_flush();
 
 private:
   struct Timed {
@@ -112,8 +118,14 @@ private:
   void begin_timed(hipStream_t s, int kind);
   void end_timed(hipStream_t s);
   void harvest();
+  void flusher_loop();
   int dev_;
   hipStream_t stream_ = nullptr;
+  std::mutex flush_mu_; // serialises TLB invalidations
+  std::thread flusher_;
+  std::mutex fl_mu_;
+  std::condition_variable fl_cv_;
+  bool fl_stop_ = false, fl_kick_ = false;
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];

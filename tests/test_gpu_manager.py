@@ -441,16 +441,15 @@ def test_unmap_leaves_its_tlb_invalidation_to_the_watcher_thread(monkeypatch):
             t[:30 * epp].fill_(77)
         torch.cuda.synchronize()
         time.sleep(0.3)                                            # prealloc refills and watcher ticks have settled
-        n0 = capi.get_stats()["tlb_shootdowns"]
+        n0, b0 = capi.get_stats()["tlb_shootdowns"], capi.get_option(capi.OPT_BACKGROUND_SHOOTDOWNS)
         t0 = time.perf_counter()
         m.free(ids)                                                # 10 page ids stay reserved, 20 are unmapped
         dt = time.perf_counter() - t0
-        st = capi.get_stats()
-        assert st["tlb_shootdowns"] == n0, "free() paid for the invalidation itself"
         deadline = time.time() + 2
         while capi.get_stats()["tlb_shootdowns"] == n0 and time.time() < deadline:
-            time.sleep(0.02)
-        assert capi.get_stats()["tlb_shootdowns"] == n0 + 1          # the watcher did it
+            time.sleep(0.005)
+        assert capi.get_stats()["tlb_shootdowns"] == n0 + 1          # exactly one invalidation for the batch ...
+        assert capi.get_option(capi.OPT_BACKGROUND_SHOOTDOWNS) == b0 + 1, "free() paid for the invalidation itself"
         # recycled pages come back zeroed and private
         ids2 = m.alloc(30 * 64)
         pages2 = sorted({b // 64 for b in ids2})

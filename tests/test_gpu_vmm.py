@@ -179,6 +179,7 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     assert ops.map_to_kv_tensors([5 * PAGE])
     n = capi.get_stats()["tlb_shootdowns"]
     assert ops.unmap_from_kv_tensors([5 * PAGE])
+    capi.flush_unmaps()                                                  # wait for the library's own thread
     assert capi.get_stats()["tlb_shootdowns"] == n + 1
 
 
@@ -213,6 +214,7 @@ def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, mon
                 assert bool((t[s * epp:(s + 1) * epp] == s + 1).all()), (mode, r, s)
             n1 = capi.get_stats()["tlb_shootdowns"]
             assert ops.unmap_from_kv_tensors(odd)
+            capi.flush_unmaps()                                            # lazy mode: the library's own thread does it
             assert capi.get_stats()["tlb_shootdowns"] == n1 + 1, (mode, r)   # every unmap batch invalidates
         assert ops.unmap_from_kv_tensors(even)
         ops.shutdown_kvcached()
