@@ -84,7 +84,11 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              was invalid is never cached on GFX9+, so mapping an unbacked slot needs none;
  *                              KVCACHED_MAP_SHOOTDOWN=always invalidates after every map batch regardless). On
  *                              ROCm 7.2 / MI355X the VMM calls alone leave stale translations behind
- *                              (DESIGN.md §4.3); 0 only for measurements.
+ *                              (DESIGN.md §4.3); 0 only for measurements. The invalidation an unmap batch owes is
+ *                              performed at once by a thread of the library (KVCACHED_ASYNC_SHOOTDOWN, default true;
+ *                              compat mode and imported pages invalidate inside the call); kvc_flush_unmaps()
+ *                              returns when nothing is owed or in flight; kvc_get_option(111) counts the
+ *                              invalidations done off the callers' threads.
  *   KVC_OPT_DEFER_UNMAP_SHOOTDOWN 1 = the invalidation owed by an unmap batch whose pages all go back
  *                              to the library's own handle pool waits for the next map batch (which invalidates
  *                              before it touches anything) or for the moment handles are given back to the
