@@ -358,7 +358,7 @@ int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, 
 
 void GpuContext::ensure_flushed() {
   std::lock_guard<std::mutex> g(flush_mu_);
-  if (tlb_stale().load()) tlb_shootdown();
+  if (tlb_stale().load()) do_shootdown();
 }
 
 void GpuContext::request_async_flush() {
@@ -390,8 +390,14 @@ void GpuContext::flusher_loop() {
   }
 }
 
-// Callers either hold flush_mu_ (ensure_flushed) or want an unconditional invalidation of their own.
+// Unconditional invalidation. Serialised with ensure_flushed(): the flag is cleared when an invalidation STARTS, so
+// whoever finds it clear must be able to rely on that invalidation having finished - both take flush_mu_.
 void GpuContext::tlb_shootdown() {
+  std::lock_guard<std::mutex> g(flush_mu_);
+  do_shootdown();
+}
+
+void GpuContext::do_shootdown() {
   tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
   if (!options().tlb_shootdown.load()) return;
   const int64_t t0 = now_ns();

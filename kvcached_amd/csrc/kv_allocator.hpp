@@ -119,6 +119,7 @@ private:
   void end_timed(hipStream_t s);
   void harvest();
   void flusher_loop();
+  void do_shootdown(); // needs flush_mu_
   int dev_;
   hipStream_t stream_ = nullptr;
   std::mutex flush_mu_; // serialises TLB invalidations
