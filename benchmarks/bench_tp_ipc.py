@@ -12,6 +12,12 @@ The reference publishes 2.10 ms (contiguous) / 35.96 ms (non-contiguous) for ONE
 asyncio.run per call) is ~1.5-2 ms of that.
 
     python benchmarks/bench_tp_ipc.py [--workers 1,2,4] [--layers 32] [--iters 30]
+    python benchmarks/bench_tp_ipc.py --shared-pool [--workers 1,3]     # the north-star TP sharing mode
+
+--shared-pool: this process is rank 0 AND the scheduler: it backs n page ids itself, exports one dmabuf fd per 2 MiB
+slot, ships them with SCM_RIGHTS over the workers' sockets and the W peers (ranks 1..W) import and map the SAME
+physical pages at the same offsets (`share_mapped_slots`); unmap goes to all ranks. On the 1-GPU box the peers share
+the device (what is measured is the export/ship/import/map machinery, not xGMI).
 """
 from __future__ import annotations
 
@@ -44,12 +50,69 @@ def worker(rank: int, n_gpus: int, layers: int, per_layer: int, ipc: str, ready,
     vmm_ops.shutdown_kvcached()
 
 
+def shared_pool(args):
+    ipc = f"kvc_tpshare_{os.getpid()}"
+    os.environ["KVCACHED_IPC_NAME"] = ipc
+    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    import torch
+    n_gpus = torch.cuda.device_count()
+    torch.cuda.set_device(0)
+    from kvcached_amd import tp_ipc_util as tp
+    from kvcached_amd import vmm_ops
+    ctx = mp.get_context("spawn")
+    per_layer = 256 * PAGE
+    vmm_ops.init_kvcached("cuda:0", PAGE, False)
+    vmm_ops.create_kv_tensors(per_layer * 2, 1, "cuda:0", args.layers, 2, 0, False)
+    tp.start_worker_listener_thread(0)                 # rank 0's own listener: broadcasts reach this process too
+    for W in [int(x) for x in args.workers.split(",")]:
+        ready, stop = ctx.Queue(), ctx.Event()
+        procs = [ctx.Process(target=worker, args=(r, n_gpus, args.layers, per_layer, ipc, ready, stop)) for r in range(1, W + 1)]
+        for p in procs:
+            p.start()
+        for _ in procs:
+            ready.get(timeout=180)
+        tp_size = W + 1
+        assert tp.broadcast_kv_tensors_created(tp_size)
+        res = {"mode": "shared pool: rank 0 backs + exports, peers import + map the same pages", "peers": W,
+               "gpus_visible": n_gpus, "layers": args.layers}
+        for n in (1, 8):
+            t_back, t_share, t_unmap = [], [], []
+            for it in range(args.iters):
+                offs = [((it * n + i) % 192) * PAGE for i in range(n)]
+                t0 = time.perf_counter()
+                assert vmm_ops.map_to_kv_tensors(offs)
+                t1 = time.perf_counter()
+                tp.share_mapped_slots(tp_size, offs, pp_rank=0, group_id=0, src_rank=0)
+                t2 = time.perf_counter()
+                tp.broadcast_unmap_from_kv_tensors(tp_size, offs)
+                t3 = time.perf_counter()
+                t_back.append(t1 - t0), t_share.append(t2 - t1), t_unmap.append(t3 - t2)
+            slots = n * args.layers * 2
+            res[f"{n}_page_ids"] = {"slots_2MiB": slots,
+                                    "rank0_back_ms_p50": round(statistics.median(t_back) * 1e3, 3),
+                                    "export_ship_import_map_on_all_peers_ms_p50": round(statistics.median(t_share) * 1e3, 3),
+                                    "us_per_slot_per_peer": round(statistics.median(t_share) * 1e6 / slots / W, 2),
+                                    "unmap_all_ranks_ms_p50": round(statistics.median(t_unmap) * 1e3, 3)}
+        print(json.dumps(res), flush=True)
+        tp._channels.close()
+        stop.set()
+        for p in procs:
+            p.join(timeout=60)
+    vmm_ops.shutdown_kvcached()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workers", default="1,2,4")
+    ap.add_argument("--workers", default=None)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--shared-pool", action="store_true")
     args = ap.parse_args()
+    if args.shared_pool:
+        args.workers = args.workers or "1,3"
+        return shared_pool(args)
+    args.workers = args.workers or "1,2,4"
     ipc = f"kvc_tpbench_{os.getpid()}"
     os.environ["KVCACHED_IPC_NAME"] = ipc
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")

@@ -352,6 +352,33 @@ public:
     }
     return a.handle;
   }
+  // The peer's side of the cross-process pool: take a dmabuf fd of somebody else's buffer into OUR KFD process
+  // (AMDKFD_IOC_IMPORT_DMABUF - the kernel then tracks it like our own when this process is evicted and restored) and
+  // into DRM, like create(). The handle is released with forget() like one of ours. 4.3 us per buffer instead of the
+  // 7 us of hsa_amd_vmem_import_shareable_handle + map + set_access. Throws GpuError.
+  phys_handle_t import_fd(int dmabuf_fd) {
+    KfdImport m{};
+    m.gpu_id = gpu_id_;
+    m.dmabuf_fd = (uint32_t)dmabuf_fd;
+    if (kfd_ioctl(kKfdImport, &m) != 0) throw GpuError(std::string("AMDKFD_IOC_IMPORT_DMABUF failed: ") + strerror(errno));
+    KfdExport e{};
+    e.handle = m.handle;
+    e.flags = O_CLOEXEC | O_RDWR;
+    ImportResult res{};
+    int r = kfd_ioctl(kKfdExport, &e) != 0 ? -errno : 0;
+    if (r == 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, e.dmabuf_fd, &res) : -ENODEV;
+      ::close((int)e.dmabuf_fd);
+      if (r == 0 && res.bo) bo_[m.handle] = Entry{res.bo, true};
+    }
+    if (r != 0 || !res.bo) {
+      KfdFree f{m.handle};
+      (void)kfd_ioctl(kKfdFree, &f);
+      throw GpuError(std::string("taking an imported buffer into DRM failed: ") + strerror(r < 0 ? -r : EIO));
+    }
+    return m.handle;
+  }
   // A dmabuf fd of a buffer made by create() (for the cross-process pool); -1 if `h` is not one.
   int export_fd(phys_handle_t h) {
     {
@@ -394,8 +421,12 @@ private:
     uint64_t handle;
     uint32_t flags, dmabuf_fd;
   };
+  struct KfdImport { // kfd_ioctl_import_dmabuf_args
+    uint64_t va_addr, handle;
+    uint32_t gpu_id, dmabuf_fd;
+  };
   static constexpr unsigned long kKfdAlloc = _IOWR('K', 0x16, KfdAlloc), kKfdFree = _IOW('K', 0x17, KfdFree),
-                                 kKfdExport = _IOWR('K', 0x24, KfdExport);
+                                 kKfdExport = _IOWR('K', 0x24, KfdExport), kKfdImport = _IOWR('K', 0x1D, KfdImport);
   // VRAM | WRITABLE | PUBLIC | NO_SUBSTITUTE, va 0: exactly what ROCr passes for hsa_amd_vmem_handle_create on the
   // coarse-grained device pool (its calls logged by tools/kfd_alloc_probe.cpp, profiles/r01_kfd_alloc_probe.log)
   static constexpr uint32_t kKfdVramFlags = (1u << 31) | (1u << 29) | (1u << 28) | 1u;

@@ -1558,6 +1558,8 @@ std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by 
 }
 static phys_handle_t import_posix_fd(int fd) {
   if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
+  if (vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && env_bool("KVCACHED_DRM_KFD_IMPORT", true))
+    return DrmVm::instance().import_fd(fd); // straight into KFD + DRM: mapped with one ioctl like our own pages
   if (vmm_uses_rocr()) { // ROCr takes the dmabuf fd by value
     hsa_amd_vmem_alloc_handle_t hh{};
     HSA_CHECK(hsa_amd_vmem_import_shareable_handle(fd, &hh));
