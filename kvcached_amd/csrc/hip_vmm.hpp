@@ -399,6 +399,11 @@ public:
   // 0 or a negative errno. The kernel serialises page-table edits per VM; no lock of ours is held across the ioctl.
   int map(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpMap); }
   int unmap(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpUnmap); }
+  // Drop EVERY mapping inside [va, va+size) with one ioctl (AMDGPU_VA_OP_CLEAR; the kernel walks its interval tree:
+  // 1.5-1.7 us per mapping for runs of 8 and more against 2.1 for one UNMAP each, tools/drm_vmm_probe.cpp). The caller
+  // guarantees that everything mapped in the range is its own and meant to go.
+  bool can_clear() const { return api_.bo_va_op_raw != nullptr && dev_ != nullptr; }
+  int clear(void *va, size_t size) { return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpClear); }
 
 private:
   struct ImportResult { // struct amdgpu_bo_import_result
@@ -461,13 +466,14 @@ private:
     return 0;
   }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
-  static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2; // AMDGPU_VA_OP_MAP / _UNMAP
+  static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR
   struct Api {
     int (*device_initialize)(int, uint32_t *, uint32_t *, void **) = nullptr;
     int (*device_deinitialize)(void *) = nullptr;
     int (*bo_import)(void *, int, uint32_t, ImportResult *) = nullptr;
     int (*bo_free)(void *) = nullptr;
     int (*bo_va_op)(void *, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t) = nullptr;
+    int (*bo_va_op_raw)(void *, void *, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t) = nullptr; // optional
   };
 
   bool load_api(std::string *why) {
@@ -483,6 +489,7 @@ private:
     a.bo_import = reinterpret_cast<decltype(a.bo_import)>(dlsym(lib, "amdgpu_bo_import"));
     a.bo_free = reinterpret_cast<decltype(a.bo_free)>(dlsym(lib, "amdgpu_bo_free"));
     a.bo_va_op = reinterpret_cast<decltype(a.bo_va_op)>(dlsym(lib, "amdgpu_bo_va_op"));
+    a.bo_va_op_raw = reinterpret_cast<decltype(a.bo_va_op_raw)>(dlsym(lib, "amdgpu_bo_va_op_raw"));
     if (!a.device_initialize || !a.device_deinitialize || !a.bo_import || !a.bo_free || !a.bo_va_op) {
       *why = "libdrm_amdgpu.so.1 lacks an expected symbol";
       return false;
@@ -651,6 +658,12 @@ inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
     HSA_CHECK(hsa_amd_vmem_unmap(va, size));
   else
     HIP_CHECK(hipMemUnmap(va, size));
+}
+// One call for a run of slots that are all direct DRM mappings of ours (drm backend only; the caller checked).
+inline void vmm_unmap_run(void *va, size_t size) {
+  tlb_stale().store(true);
+  const int r = DrmVm::instance().clear(va, size);
+  if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA clear failed: ") + strerror(r < 0 ? -r : r));
 }
 inline bool vmm_try_unmap(void *va, size_t size, phys_handle_t h = 0) {
   tlb_stale().store(true);

@@ -666,6 +666,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_unmap = env_bool("KVCACHED_ASYNC_UNMAP", false) ? 1 : 0;
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   options().hip_reg_group_mb = std::max<int64_t>(0, env_i64("KVCACHED_HIP_REG_GROUP_MB", 64));
+  options().clear_run_slots = std::max<int64_t>(0, env_i64("KVCACHED_DRM_CLEAR_RUN", 16));
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -1479,17 +1480,55 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     run_len = 0;
   };
   u.own.reserve(slots.size());
-  for (auto &s : slots) {
+  // drm backend, lazy regions: slots of this batch that are neighbours in VA go in runs - one CLEAR ioctl per run of up
+  // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
+  // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
+  std::vector<uint8_t> cleared(slots.size(), 0);
+  const size_t max_clear = (size_t)options().clear_run_slots.load();
+  if (max_clear >= 2 && slots.size() >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
+    std::vector<uint32_t> order;
+    order.reserve(slots.size());
+    for (uint32_t i = 0; i < slots.size(); ++i) {
+      const KvRegion &r = *slots[i].region;
+      const uint8_t m = r.mapped[slots[i].index];
+      if ((m == 1 || m == 2) && !r.backfilled && vmm_direct_bo(r.handle[slots[i].index])) order.push_back(i);
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+      return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
+    });
+    for (size_t i = 1; i < order.size(); ++i) // the same slot listed twice (tolerated: logged and skipped below): no runs
+      if (slots[order[i]].region == slots[order[i - 1]].region && slots[order[i]].index == slots[order[i - 1]].index) {
+        order.clear();
+        break;
+      }
+    for (size_t i = 0; i < order.size();) {
+      size_t j = i + 1;
+      while (j < order.size() && j - i < max_clear && slots[order[j]].region == slots[order[i]].region &&
+             slots[order[j]].index == slots[order[j - 1]].index + 1)
+        ++j;
+      if (j - i >= 2) {
+        KvRegion &r = *slots[order[i]].region;
+        const int64_t t0 = now_ns();
+        vmm_unmap_run(r.base + slots[order[i]].index * ps, (j - i) * ps);
+        stats().t_unmap += now_ns() - t0;
+        for (size_t k = i; k < j; ++k) cleared[order[k]] = 1;
+      }
+      i = j;
+    }
+  }
+  for (size_t si = 0; si < slots.size(); ++si) {
+    const Slot &s = slots[si];
     KvRegion &r = *s.region;
     if (r.mapped[s.index] != 1 && r.mapped[s.index] != 2) { // reference: log + skip (ftensor.cpp:124-127)
       KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", s.index);
       continue;
     }
     char *va = r.base + s.index * ps;
-    const int64_t t0 = now_ns();
-    vmm_unmap(va, ps, r.handle[s.index]);
-    const int64_t t1 = now_ns();
-    stats().t_unmap += t1 - t0;
+    if (!cleared[si]) {
+      const int64_t t0 = now_ns();
+      vmm_unmap(va, ps, r.handle[s.index]);
+      stats().t_unmap += now_ns() - t0;
+    }
     if (r.mapped[s.index] == 1)
       u.own.push_back(Phys{r.handle[s.index], r.seq[s.index]});
     else

@@ -28,6 +28,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -191,6 +192,7 @@ int main(int argc, char **argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 1024;
   const int rounds = argc > 2 ? atoi(argv[2]) : 4;
   g_mode = argc > 3 ? atoi(argv[3]) : 0;
+  const int clear_run = argc > 4 ? atoi(argv[4]) : 0; // > 0: unmap with AMDGPU_VA_OP_CLEAR over runs of this many slots
   const size_t PAGE = 2u << 20;
   CK(hipSetDevice(0));
   CK(hipFree(nullptr));
@@ -371,7 +373,12 @@ int main(int argc, char **argv) {
     stamp_pages<<<dim3(8, n), 256, 0, s>>>((unsigned *)va, PAGE / 4, tags);
     CK(hipStreamSynchronize(s));
     double d = now_us();
-    for (int i = 0; i < n; i++) DK(amdgpu_bo_va_op(bo[handle_at(i, round)], 0, PAGE, (uint64_t)(va + (size_t)i * PAGE), 0, AMDGPU_VA_OP_UNMAP));
+    if (clear_run > 0) { // one ioctl drops every mapping in the range (the kernel walks its interval tree)
+      for (int i = 0; i < n; i += clear_run)
+        DK(amdgpu_bo_va_op_raw(dev, nullptr, 0, (uint64_t)std::min(clear_run, n - i) * PAGE, (uint64_t)(va + (size_t)i * PAGE), 0, AMDGPU_VA_OP_CLEAR));
+    } else {
+      for (int i = 0; i < n; i++) DK(amdgpu_bo_va_op(bo[handle_at(i, round)], 0, PAGE, (uint64_t)(va + (size_t)i * PAGE), 0, AMDGPU_VA_OP_UNMAP));
+    }
     double e = now_us();
     tlb_shootdown();
     printf("round %d: map %.2f  unmap %.2f us/page (shootdown %.0f us);  words that did not follow their handle: %llu\n", round,
