@@ -133,7 +133,8 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         else:
             mapper, unmapper = capi.map_to_kv_tensors, capi.unmap_from_kv_tensors
         if prefault:
-            for b in range(window):
+            for b in range(window * int(os.environ.get("KVC_BENCH_SETUP_SWEEPS", "1"))):
+                b %= window
                 offs = batch_offsets(b, slot=slot)
                 mapper(offs)
                 unmapper(offs)
