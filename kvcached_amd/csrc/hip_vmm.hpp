@@ -69,9 +69,11 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 // directly, map + set_access + unmap cost 2.3 + 3.0 + 2.8 us per 2 MiB mapping instead of 3.1 + 3.3 + 14.5
 // (tools/hsa_vmm_probe.cpp, same box). The price: HIP never learns about such mappings. Kernels (raw pointers),
 // device-to-device hipMemcpy, hipMemset and hipPointerGetAttributes work on them; a host<->device hipMemcpy takes
-// the pointer for pageable host memory and crashes. Hence: HIP is the default backend (every torch operation
-// works on the KV tensors), KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only.
-using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer) or hsa_amd_vmem_alloc_handle_t::handle
+// the pointer for pageable host memory and crashes. Hence the hybrid backend (slots registered with HIP once, every
+// torch operation works on the KV tensors) and, on top of it, the default drm backend (DrmVm below);
+// KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only, =hip is HIP's API alone.
+using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer), hsa_amd_vmem_alloc_handle_t::handle, or
+                                // (drm backend, pages allocated straight from KFD) KFD's buffer handle
 
 enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2, kVmmDrm = 3 };
 // kVmmHybrid: VA reserved through HIP and every slot registered with HIP once (hipMemMap of a placeholder handle,
@@ -83,9 +85,10 @@ inline std::atomic<int> &vmm_backend() { // set by KvAllocator::init from KVCACH
   return v;
 }
 inline bool vmm_uses_rocr() { return vmm_backend().load() != kVmmHip; }
-// kVmmDrm: hybrid, plus this process's own pages are mapped and unmapped with ONE ioctl each (DrmVm below) instead of
-// ROCr's export + import + mmap + GEM_VA (+ GEM_CLOSE) per call. Everything else (aliases, imported handles,
-// registration with HIP, export) is the hybrid backend's.
+// kVmmDrm: hybrid, plus this process's own pages - and pages imported from a peer - are mapped with ONE ioctl each
+// and unmapped with one ranged ioctl per run of neighbours (DrmVm below) instead of ROCr's export + import + mmap +
+// GEM_VA (+ GEM_CLOSE) per call, and are allocated straight from KFD. Zero aliases (compat mode) and the registration
+// with HIP stay the hybrid backend's.
 inline bool vmm_hip_registered() {
   const int b = vmm_backend().load();
   return b == kVmmHybrid || b == kVmmDrm;
