@@ -220,6 +220,52 @@ def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, mon
         ops.shutdown_kvcached()
 
 
+def test_unmap_batches_with_runs_of_neighbours(vmm):
+    """drm backend: an unmap batch is sorted and every run of adjacent slots goes in one ranged ioctl (<= 16 slots per
+    call). Whatever the listing order, the run lengths or a slot listed twice: exactly the listed slots
+    lose their pages, their neighbours keep theirs (data intact), and every freed slot can be backed again."""
+    import random
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=160 * MiB, backfill=False, kv=1, unified=True)
+    t, epp = ts[0], PAGE // 2
+    n = 80
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([i * PAGE for i in range(n)])
+    for i in range(n):
+        t[i * epp:(i + 1) * epp].fill_(i + 1)
+    torch.cuda.synchronize()
+    rng = random.Random(5)
+    # runs of 1, 2, 3, 16, 17 (split 16 + 1) and 20 slots, with gaps of live neighbours in between
+    victims = [0] + [2, 3] + [5, 6, 7] + list(range(9, 25)) + list(range(26, 43)) + list(range(44, 64))
+    listed = victims[:]
+    rng.shuffle(listed)
+    assert ops.unmap_from_kv_tensors([i * PAGE for i in listed])
+    capi.flush_unmaps()
+    assert capi.get_stats()["pages_unmapped"] == len(victims)
+    live = [i for i in range(n) if i not in set(victims)]
+    for i in live:
+        assert bool((t[i * epp:(i + 1) * epp] == i + 1).all()), i          # neighbours of every run untouched
+    # a slot listed twice is tolerated like in the reference (logged, skipped), the rest of the batch goes through
+    dup = [70, 71, 72, 71, 73]
+    assert ops.unmap_from_kv_tensors([i * PAGE for i in dup])
+    capi.flush_unmaps()
+    assert capi.get_stats()["pages_unmapped"] == len(victims) + 4
+    for i in (69, 74):
+        assert bool((t[i * epp:(i + 1) * epp] == i + 1).all())
+    # everything freed can be backed again (the ranges really are empty) and comes back zeroed
+    again = victims + [70, 71, 72, 73]
+    rng.shuffle(again)
+    assert ops.map_to_kv_tensors([i * PAGE for i in again])
+    for i in again:
+        assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0, i
+    for i in live:
+        if i not in (70, 71, 72, 73):
+            assert bool((t[i * epp:(i + 1) * epp] == i + 1).all()), i
+    assert ops.unmap_from_kv_tensors([i * PAGE for i in range(n)])
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_reinit_never_writes_through_a_translation_of_a_previous_life(vmm):
     """Map batches no longer invalidate by themselves, so every path that removes a LIVE translation must: region
     teardown (pages and zero aliases), the init self tests, rollbacks. Otherwise: a region is torn down, its physical
