@@ -94,6 +94,22 @@ def main():
         if w:
             bad += w
             print(f"[soak] request {rid}: {w} signature words wrong over {len(ids)} blocks", file=sys.stderr)
+            # what is there instead? (decoded: layer, request, block; ~x = a V-half signature; 0 = zero fill)
+            sig = (rid << 24) + ids_t
+            base = ids_t * (BLOCK_BYTES // 8)
+            shown = 0
+            for layer, wd in enumerate(words):
+                val = sig + (layer << 56)
+                for off, want, tag in ((0, val, "K.first"), (last, val, "K.last"), (v_off, ~val, "V.first"), (v_off + last, ~val, "V.last")):
+                    got = wd[base + off]
+                    idx = torch.nonzero(got != want).flatten()[:3].tolist()
+                    for i in idx:
+                        g, wv = int(got[i]), int(want[i])
+                        dec = lambda x: (x >> 56 & 0xff, (x >> 24) & 0xffffffff, x & 0xffffff)
+                        print(f"    layer {layer} {tag} block {int(ids_t[i])} (page {int(ids_t[i]) // 64}): got {g:#x} {dec(g)} / ~{dec(~g)}  want {wv:#x}", file=sys.stderr)
+                        shown += 1
+                if shown > 12:
+                    break
         counts["blocks_verified"] += len(ids)
         m.free(ids)
         counts["free"] += 1

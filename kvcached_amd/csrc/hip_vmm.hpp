@@ -35,6 +35,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -74,6 +75,14 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 // KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only, =hip is HIP's API alone.
 using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer), hsa_amd_vmem_alloc_handle_t::handle, or
                                 // (drm backend, pages allocated straight from KFD) KFD's buffer handle
+
+// Piece ids (drm backend, KVCACHED_PHYS_CHUNK_PAGES > 1): physical memory is allocated in chunks of k pages and a
+// handle names ONE page-sized piece of a chunk: the chunk's buffer handle (KFD handles are < 2^48) with the piece index
+// in the top byte. With k = 1 - every other backend, and the default - a piece id IS the handle.
+constexpr int kPieceShift = 56;
+inline phys_handle_t piece_id(phys_handle_t chunk, unsigned piece) { return chunk | (static_cast<uint64_t>(piece) << kPieceShift); }
+inline phys_handle_t chunk_of(phys_handle_t h) { return h & ((1ull << kPieceShift) - 1); }
+inline unsigned piece_of(phys_handle_t h) { return static_cast<unsigned>(h >> kPieceShift); }
 
 enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2, kVmmDrm = 3 };
 // kVmmHybrid: VA reserved through HIP and every slot registered with HIP once (hipMemMap of a placeholder handle,
@@ -400,11 +409,40 @@ public:
     return bo_.size();
   }
   // 0 or a negative errno. The kernel serialises page-table edits per VM; no lock of ours is held across the ioctl.
-  int map(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpMap); }
-  int unmap(void *bo, void *va, size_t size) { return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpUnmap); }
+  // `offset`: where in the buffer the mapping starts (GEM_VA honours it; HIP rejects one, ROCr ignores it).
+  int map(void *bo, void *va, size_t size, uint64_t offset = 0) {
+    return api_.bo_va_op(bo, offset, size, reinterpret_cast<uint64_t>(va), 0, kVaOpMap);
+  }
+  // UNMAP needs the exact extent of a mapping; CLEAR drops whatever is mapped in the range, splitting a larger mapping
+  // if need be (a page that was mapped together with its neighbours in one ioctl) at the same cost - used when available.
+  int unmap(void *bo, void *va, size_t size) {
+    if (can_clear()) return clear(va, size);
+    return api_.bo_va_op(bo, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpUnmap);
+  }
   // Drop EVERY mapping inside [va, va+size) with one ioctl (AMDGPU_VA_OP_CLEAR; the kernel walks its interval tree:
   // 1.5-1.7 us per mapping for runs of 8 and more against 2.1 for one UNMAP each, tools/drm_vmm_probe.cpp). The caller
   // guarantees that everything mapped in the range is its own and meant to go.
+  // After pieces were CLEARed out of a larger mapping of `bo`: the kernel keeps what is left of that mapping, but the
+  // page-table entries of the survivors still carry the FRAGMENT size of the original extent - the TLB may go on
+  // translating the whole extent, hole included, from a neighbour's entry (seen as a slot that showed its previous
+  // page after being backed afresh: benchmarks/soak_manager.py with chunked memory). The kernel rewrites the
+  // remainders (with fragments that fit them) the next time it updates this buffer's mappings, i.e. on any MAP of it:
+  // map one page of it at a scratch VA and drop that again. The caller invalidates the TLBs afterwards.
+  bool refresh_mappings_of(void *bo, size_t page_bytes) {
+    std::lock_guard<std::mutex> g(scratch_mu_);
+    if (!scratch_va_ || scratch_bytes_ < page_bytes) {
+      if (scratch_va_) (void)hipMemAddressFree(scratch_va_, scratch_bytes_);
+      scratch_va_ = nullptr;
+      if (hipMemAddressReserve(&scratch_va_, page_bytes, page_bytes, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        scratch_va_ = nullptr;
+        return false;
+      }
+      scratch_bytes_ = page_bytes;
+    }
+    if (map(bo, scratch_va_, page_bytes, 0) != 0) return false;
+    return clear(scratch_va_, page_bytes) == 0;
+  }
   bool can_clear() const { return api_.bo_va_op_raw != nullptr && dev_ != nullptr; }
   int clear(void *va, size_t size) { return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpClear); }
 
@@ -541,6 +579,9 @@ private:
   int kfd_fd_ = -1;      // our own open of /dev/kfd (same kfd_process as ROCr's)
   uint32_t gpu_id_ = 0;  // KFD's id of the device
   std::unordered_map<phys_handle_t, Entry> bo_; // ROCr handle or KFD handle -> buffer object
+  std::mutex scratch_mu_;
+  void *scratch_va_ = nullptr; // one page of reserved VA for refresh_mappings_of()
+  size_t scratch_bytes_ = 0;
 };
 
 inline hipMemAllocationProp make_alloc_prop(int dev, bool exportable) {
@@ -598,11 +639,18 @@ inline bool vmm_try_release(phys_handle_t h) {
   if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }
-inline void *vmm_direct_bo(phys_handle_t h) { return vmm_backend() == kVmmDrm ? DrmVm::instance().find(h) : nullptr; }
+inline void *vmm_direct_bo(phys_handle_t h) { return vmm_backend() == kVmmDrm ? DrmVm::instance().find(chunk_of(h)) : nullptr; }
+// `count` pieces of one chunk with consecutive indices, starting with `h_first`, behind `count` adjacent slots: ONE ioctl.
+inline void vmm_map_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first) {
+  void *bo = vmm_direct_bo(h_first);
+  if (!bo) throw GpuError("vmm_map_pieces: not a direct DRM buffer");
+  const int r = DrmVm::instance().map(bo, va, count * piece_bytes, static_cast<uint64_t>(piece_of(h_first)) * piece_bytes);
+  if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
+}
 // Returns whether the mapping still needs vmm_set_access (a DRM mapping is made readable+writable in the same ioctl).
 inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
   if (void *bo = vmm_direct_bo(h)) {
-    const int r = DrmVm::instance().map(bo, va, size);
+    const int r = DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece_of(h)) * size);
     if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
     return false;
   }
@@ -613,7 +661,7 @@ inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
   return true;
 }
 inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
-  if (void *bo = vmm_direct_bo(h)) return DrmVm::instance().map(bo, va, size) == 0;
+  if (void *bo = vmm_direct_bo(h)) return DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece_of(h)) * size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
   return hipMemMap(va, size, 0, as_hip(h), 0) == hipSuccess;
 }
@@ -650,8 +698,14 @@ inline std::atomic<bool> &tlb_stale() {
 }
 // `h`: the handle mapped at `va`, when the caller knows it (needed to undo a direct DRM mapping; 0 = an alias or
 // a range, which are always ROCr's / HIP's).
+// The flag is raised AFTER the driver call (and before it, for good measure): an invalidation that starts between
+// "flag set" and "translation removed" clears the flag without covering this unmap.
+struct StaleAfter {
+  StaleAfter() { tlb_stale().store(true); }
+  ~StaleAfter() { tlb_stale().store(true); }
+};
 inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
-  tlb_stale().store(true);
+  StaleAfter mark;
   if (void *bo = h ? vmm_direct_bo(h) : nullptr) {
     const int r = DrmVm::instance().unmap(bo, va, size);
     if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA unmap failed: ") + strerror(r < 0 ? -r : r));
@@ -664,12 +718,12 @@ inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
 }
 // One call for a run of slots that are all direct DRM mappings of ours (drm backend only; the caller checked).
 inline void vmm_unmap_run(void *va, size_t size) {
-  tlb_stale().store(true);
+  StaleAfter mark;
   const int r = DrmVm::instance().clear(va, size);
   if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA clear failed: ") + strerror(r < 0 ? -r : r));
 }
 inline bool vmm_try_unmap(void *va, size_t size, phys_handle_t h = 0) {
-  tlb_stale().store(true);
+  StaleAfter mark;
   if (void *bo = h ? vmm_direct_bo(h) : nullptr) return DrmVm::instance().unmap(bo, va, size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_unmap(va, size) == HSA_STATUS_SUCCESS;
   const bool ok = hipMemUnmap(va, size) == hipSuccess;
@@ -706,8 +760,10 @@ struct Phys {
 // so an idle engine does not starve a co-located one). Eviction is oldest-created-first.
 class PhysPool {
 public:
-  PhysPool(int dev, size_t granule, bool exportable, VmmCounters *ctr)
-      : dev_(dev), granule_(granule), exportable_(exportable), ctr_(ctr) {}
+  // `unit`: pages per handle (1, or k when the handles are chunks carved up by a PiecePool): the created/released
+  // counters stay in pages; reuse is then counted per piece by the PiecePool.
+  PhysPool(int dev, size_t granule, bool exportable, VmmCounters *ctr, unsigned unit = 1)
+      : dev_(dev), granule_(granule), exportable_(exportable), ctr_(ctr), unit_(unit) {}
   ~PhysPool() { drain(0); }
 
   size_t granule() const { return granule_; }
@@ -725,7 +781,7 @@ public:
     *out = Phys{it->second, it->first};
     idle_.erase(it);
     low_water_ = std::min(low_water_, idle_.size());
-    ctr_->reused++;
+    if (unit_ == 1) ctr_->reused++;
     return true;
   }
 
@@ -738,7 +794,7 @@ public:
         Phys p{it->second, it->first};
         idle_.erase(it);
         low_water_ = std::min(low_water_, idle_.size());
-        ctr_->reused++;
+        if (unit_ == 1) ctr_->reused++;
         *recycled = true;
         return p;
       }
@@ -748,7 +804,7 @@ public:
       hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
     p.h = vmm_create(dev_, granule_, exportable_);
     p.seq = next_seq_.fetch_add(1) + 1;
-    ctr_->created++;
+    ctr_->created += unit_;
     *recycled = false;
     return p;
   }
@@ -866,7 +922,7 @@ public:
     std::sort(v.begin(), v.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; });
     for (auto &p : v) {
       if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
-      ctr_->released++;
+      ctr_->released += unit_;
     }
     (void)hipGetLastError();
   }
@@ -876,6 +932,7 @@ private:
   size_t granule_;
   bool exportable_;
   VmmCounters *ctr_;
+  unsigned unit_ = 1;
   size_t cap_handles_ = 0;
   std::function<void()> before_driver_release_;
   std::atomic<bool> defer_eviction_{false};
@@ -884,6 +941,138 @@ private:
   std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle
   size_t low_water_ = 0;                         // smallest idle_ size since window_start_ns_
   int64_t window_start_ns_ = 0;
+};
+
+// Page-sized pieces out of a PhysPool of chunks (k pages each; k = 1: a plain pass-through, which is the default and
+// the only mode of the non-drm backends). GEM_VA maps at an offset into a buffer, so any piece can back any slot, and a
+// run of adjacent slots backed by adjacent pieces of one chunk is ONE ioctl (tools/drm_chunk_probe.cpp: 0.18 us per
+// page for runs of 16 against 2.2). Whole idle chunks live in the PhysPool (cap, decay, pressure, eviction all work on
+// chunks); chunks with some pieces out are tracked here and go back to it when their last piece returns. Single pieces
+// are served from partly used chunks first, so that whole chunks stay whole.
+class PiecePool {
+public:
+  PiecePool(PhysPool *chunks, size_t piece_bytes, unsigned k, VmmCounters *ctr)
+      : chunks_(chunks), piece_bytes_(piece_bytes), k_(k), ctr_(ctr), full_(k >= 64 ? ~0ull : ((1ull << k) - 1)) {}
+  PhysPool *chunks() const { return chunks_; }
+  unsigned pieces_per_chunk() const { return k_; }
+
+  // Up to `want` pieces with consecutive indices in one chunk; at least one unless nothing is idle and !may_create
+  // (then 0). *recycled: the memory may hold old data.
+  size_t acquire_run(size_t want, Phys *out, bool *recycled, bool may_create) {
+    if (k_ == 1) {
+      if (may_create) {
+        out[0] = chunks_->acquire(recycled);
+        return 1;
+      }
+      *recycled = true;
+      return chunks_->try_acquire_idle(&out[0]) ? 1 : 0;
+    }
+    want = std::min<size_t>(std::max<size_t>(want, 1), k_);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      size_t looked = 0;
+      for (auto it = partial_.begin(); it != partial_.end() && looked < 8; ++it, ++looked) { // a partly used chunk with room
+        Chunk &c = tracked_[*it];
+        const int first = find_run(c.free_mask, (unsigned)want);
+        if (first < 0) continue;
+        const phys_handle_t h = *it;
+        const unsigned old = take(h, c, (unsigned)first, (unsigned)want, out);
+        *recycled = old > 0;
+        ctr_->reused += old;
+        return want;
+      }
+    }
+    Phys c;
+    bool rec = true;
+    if (!chunks_->try_acquire_idle(&c)) {
+      if (!may_create) return 0;
+      c = chunks_->acquire(&rec); // may throw: nothing of ours has changed yet
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    Chunk &t = tracked_[c.h];
+    t.seq = c.seq;
+    t.free_mask = full_;
+    t.used_mask = rec ? full_ : 0; // a chunk from the idle pool has been used all over, a new one nowhere
+    const unsigned old = take(c.h, t, 0, (unsigned)want, out);
+    *recycled = old > 0;
+    ctr_->reused += old;
+    return want;
+  }
+
+  void release(Phys p) { release_batch(&p, 1); }
+  void release_batch(Phys *ps, size_t n) {
+    if (n == 0) return;
+    if (k_ == 1) {
+      chunks_->release_batch(ps, n);
+      return;
+    }
+    std::vector<Phys> whole;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t i = 0; i < n; ++i) {
+        const phys_handle_t h = chunk_of(ps[i].h);
+        auto it = tracked_.find(h);
+        if (it == tracked_.end()) {
+          KVC_LOG(LOG_ERROR, "a piece of an unknown chunk was released");
+          continue;
+        }
+        it->second.free_mask |= 1ull << piece_of(ps[i].h);
+        if (it->second.free_mask == full_) {
+          whole.push_back(Phys{h, it->second.seq});
+          partial_.erase(h);
+          tracked_.erase(it);
+        } else {
+          partial_.insert(h);
+        }
+      }
+    }
+    if (!whole.empty()) chunks_->release_batch(whole.data(), whole.size());
+  }
+  // bytes of free pieces inside partly used chunks: ours to reuse, invisible to hipMemGetInfo
+  size_t free_piece_bytes() {
+    if (k_ == 1) return 0;
+    std::lock_guard<std::mutex> g(mu_);
+    size_t n = 0;
+    for (auto h : partial_) n += (size_t)__builtin_popcountll(tracked_[h].free_mask);
+    return n * piece_bytes_;
+  }
+
+private:
+  struct Chunk {
+    uint64_t seq = 0;
+    uint64_t free_mask = 0;
+    uint64_t used_mask = 0; // pieces that have been handed out before (their memory may hold old data)
+  };
+  // lowest start of `want` consecutive free pieces, or -1
+  int find_run(uint64_t mask, unsigned want) const {
+    uint64_t m = mask;
+    for (unsigned s = 1; s < want && m; ++s) m &= mask >> s;
+    return m ? __builtin_ctzll(m) : -1;
+  }
+  // returns how many of the pieces taken had been in use before
+  unsigned take(phys_handle_t h, Chunk &c, unsigned first, unsigned n, Phys *out) {
+    unsigned old = 0;
+    for (unsigned i = 0; i < n; ++i) {
+      const uint64_t bit = 1ull << (first + i);
+      c.free_mask &= ~bit;
+      old += (c.used_mask & bit) != 0;
+      c.used_mask |= bit;
+      out[i] = Phys{piece_id(h, first + i), c.seq};
+    }
+    if (c.free_mask)
+      partial_.insert(h);
+    else
+      partial_.erase(h);
+    return old;
+  }
+  PhysPool *chunks_;
+  size_t piece_bytes_;
+  unsigned k_;
+  VmmCounters *ctr_;
+  uint64_t full_;
+  std::mutex mu_;
+  std::unordered_map<phys_handle_t, Chunk> tracked_; // chunks with at least one piece handed out
+  std::set<phys_handle_t> partial_;                   // ... of which some pieces are free
 };
 
 } // namespace kvc

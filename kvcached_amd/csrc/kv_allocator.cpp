@@ -86,6 +86,8 @@ GpuContext::GpuContext(int dev) : dev_(dev) {
 }
 
 GpuContext::~GpuContext() {
+  piece_pools_[0].clear();
+  piece_pools_[1].clear();
   {
     std::lock_guard<std::mutex> g(fl_mu_);
     fl_stop_ = true;
@@ -124,6 +126,37 @@ PhysPool *GpuContext::pool(size_t granule, bool exportable) {
   return it->second.get();
 }
 
+PiecePool *GpuContext::pieces(size_t page_bytes, bool exportable) {
+  unsigned k = 1;
+  if (!exportable && vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && DrmVm::instance().can_clear())
+    k = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, options().phys_chunk_pages.load()));
+  PhysPool *chunks;
+  if (k == 1) {
+    chunks = pool(page_bytes, exportable);
+  } else {
+    std::lock_guard<std::mutex> g(mu_);
+    auto &m = pools_[0];
+    const size_t key = page_bytes * k + 1; // odd: cannot collide with the pool of a real granule
+    auto it = m.find(key);
+    if (it == m.end()) {
+      it = m.emplace(key, std::make_unique<PhysPool>(dev_, page_bytes * k, false, &stats().vmm, k)).first;
+      it->second->set_before_driver_release([this]() { flush_deferred_shootdown(); });
+      it->second->set_defer_eviction(housekeepers_.load() > 0);
+    }
+    it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+    chunks = it->second.get();
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  auto &pm = piece_pools_[exportable ? 1 : 0];
+  auto it = pm.find(page_bytes);
+  if (it == pm.end() || it->second->pieces_per_chunk() != k || it->second->chunks() != chunks) {
+    // (re)made at the first use after an init that changed the chunking: no region exists then, every piece is home
+    pm[page_bytes] = std::make_unique<PiecePool>(chunks, page_bytes, k, &stats().vmm);
+    it = pm.find(page_bytes);
+  }
+  return it->second.get();
+}
+
 void GpuContext::drain_pools() {
   std::vector<PhysPool *> ps;
   {
@@ -139,6 +172,8 @@ size_t GpuContext::idle_pool_bytes() {
   size_t b = 0;
   for (auto &m : pools_)
     for (auto &kv : m) b += kv.second->idle_count() * kv.second->granule();
+  for (auto &m : piece_pools_)
+    for (auto &kv : m) b += kv.second->free_piece_bytes();
   return b;
 }
 
@@ -667,6 +702,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   options().hip_reg_group_mb = std::max<int64_t>(0, env_i64("KVCACHED_HIP_REG_GROUP_MB", 64));
   options().clear_run_slots = std::max<int64_t>(0, env_i64("KVCACHED_DRM_CLEAR_RUN", 16));
+  options().phys_chunk_pages = std::min<int64_t>(64, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 1)));
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -1047,13 +1083,15 @@ void KvAllocator::destroy_region(KvRegion &r) {
     whole = vmm_try_unmap(r.base, r.size);
     if (!whole) KVC_LOG(LOG_ERROR, "unmapping the whole region %s in one call failed", r.name.c_str());
   }
-  std::vector<Phys> dead;
+  std::vector<Phys> dead, pieces; // pieces: pages that are parts of chunks (KVCACHED_PHYS_CHUNK_PAGES) go home through their pool
+  PiecePool *pp = ctx ? ctx->pieces(r.page_size, exportable_) : nullptr;
+  const bool chunked = pp && pp->pieces_per_chunk() > 1;
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.mapped[i]) continue;
     if (!whole) {
       if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
-    dead.push_back(Phys{r.handle[i], r.seq[i]});
+    (chunked && r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
   }
   std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
@@ -1072,6 +1110,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
     if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle during cleanup failed");
     stats().vmm.released++;
   }
+  if (!pieces.empty()) pp->release_batch(pieces.data(), pieces.size()); // whole chunks end up in the chunk pool (drained at shutdown)
   for (auto z : r.zero) (void)vmm_try_release(z);
   r.zero.clear();
   if (!vmm_try_address_free(r.base, r.size)) KVC_LOG(LOG_ERROR, "freeing the VA range of %s failed", r.name.c_str());
@@ -1245,6 +1284,8 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
     vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
+    if (piece_of(r.handle[s.index]) != 0 || ctx_->pieces(ps, exportable_)->pieces_per_chunk() > 1) // (see unmap_collect)
+      if (void *bo = vmm_direct_bo(r.handle[s.index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
     *out = Phys{r.handle[s.index], r.seq[s.index]};
@@ -1282,7 +1323,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   GpuContext *ctx = ctx_;
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
-  PhysPool *pool = ctx->pool(ps, exportable_);
+  PiecePool *pool = ctx->pieces(ps, exportable_);
   const bool fill = options().zero_fill.load() && !imported;
   const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
 
@@ -1343,6 +1384,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   };
 
   std::vector<Slot> kept; // async unmap: released but not yet unmapped -> simply kept, only zero-filled again
+  // Chunked physical memory (KVCACHED_PHYS_CHUNK_PAGES > 1, drm backend): the unbacked slots of the batch are collected
+  // first and then backed run by run - adjacent slots get adjacent pieces of one chunk and ONE map ioctl.
+  const bool chunked = pool->pieces_per_chunk() > 1 && !imported;
+  std::vector<Slot> fresh;
   try {
     for (auto &s : slots) {
       KvRegion &r = *s.region;
@@ -1371,13 +1416,17 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       Phys ph;
       if (imported) {
         ph = Phys{(*imported)[next_import++], 0};
-      } else if (pool->try_acquire_idle(&ph)) {
+      } else if (chunked && !r.backfilled) {
+        fresh.push_back(s); // backed below, run by run: adjacent slots share one ioctl
+        stats().t_unmap_alias += t1 - t0;
+        continue;
+      } else if (pool->acquire_run(1, &ph, &recycled, false) == 1) {
         recycled = true;
       } else if (steal_pending(ps, &ph)) { // async unmap: take the page of a released slot instead of creating one
         recycled = true;
         dirty_tlb = true;
       } else {
-        ph = pool->acquire(&recycled);
+        (void)pool->acquire_run(1, &ph, &recycled, true);
       }
       phys_handle_t h = ph.h;
       int64_t t2 = now_ns();
@@ -1413,6 +1462,45 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       run_pages.push_back(va);
     }
     flush_run();
+    if (!fresh.empty()) {
+      std::sort(fresh.begin(), fresh.end(), [](const Slot &a, const Slot &b) {
+        return a.region != b.region ? a.region < b.region : a.index < b.index;
+      });
+      std::vector<Phys> got(pool->pieces_per_chunk());
+      for (size_t i = 0; i < fresh.size();) {
+        size_t j = i + 1;
+        while (j < fresh.size() && fresh[j].region == fresh[i].region && fresh[j].index == fresh[j - 1].index + 1) ++j;
+        while (i < j) { // slots [i, j) are neighbours: as many as one chunk can serve at a time
+          KvRegion &r = *fresh[i].region;
+          const int64_t t1 = now_ns();
+          bool recycled = false;
+          size_t n = pool->acquire_run(j - i, got.data(), &recycled, false);
+          if (n == 0 && steal_pending(ps, &got[0])) n = 1; // (its unmap has set tlb_stale: flushed before the fill)
+          if (n == 0) n = pool->acquire_run(j - i, got.data(), &recycled, true);
+          const int64_t t2 = now_ns();
+          char *va = r.base + fresh[i].index * ps;
+          try {
+            vmm_map_pieces(va, ps, n, got[0].h);
+          } catch (...) {
+            pool->release_batch(got.data(), n);
+            throw;
+          }
+          stats().t_acquire += t2 - t1;
+          stats().t_map += now_ns() - t2;
+          for (size_t k = 0; k < n; ++k) {
+            const Slot &s = fresh[i + k];
+            r.handle[s.index] = got[k].h;
+            r.seq[s.index] = got[k].seq;
+            r.mapped[s.index] = 1;
+            done.push_back(s);
+            if (fill) pending.push_back(r.base + s.index * ps);
+          }
+          if (always_flush) dirty_tlb = true;
+          if (fill) launch_pending(false);
+          i += n;
+        }
+      }
+    }
     if (fill) launch_pending(true);
     if (always_flush && dirty_tlb) tlb_stale().store(true);
     ctx->ensure_flushed(); // nothing may reach the new pages through a stale translation
@@ -1430,6 +1518,8 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
       (void)vmm_try_unmap(va, ps, r.handle[it->index]);
+      if (chunked)
+        if (void *bo = vmm_direct_bo(r.handle[it->index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
       if (r.mapped[it->index] == 1)
         pool->release(Phys{r.handle[it->index], r.seq[it->index]});
       else
@@ -1480,6 +1570,11 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     run_len = 0;
   };
   u.own.reserve(slots.size());
+  // chunked physical memory: pages may have been mapped together with their neighbours in one ioctl; taking some of them
+  // out splits that mapping, and what is left of it must be rewritten (DrmVm::refresh_mappings_of) before the TLBs are
+  // invalidated
+  const bool chunked_unmap = ctx->pieces(ps, exportable_)->pieces_per_chunk() > 1;
+  std::vector<phys_handle_t> touched;
   // drm backend, lazy regions: slots of this batch that are neighbours in VA go in runs - one CLEAR ioctl per run of up
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
@@ -1535,6 +1630,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       u.imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
     ++u.n;
+    if (chunked_unmap) touched.push_back(chunk_of(r.handle[s.index]));
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();
@@ -1548,6 +1644,14 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     }
   }
   flush_run();
+  if (!touched.empty()) {
+    std::sort(touched.begin(), touched.end());
+    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+    for (auto c : touched)
+      if (void *bo = DrmVm::instance().find(c))
+        if (!DrmVm::instance().refresh_mappings_of(bo, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of a chunk failed");
+    tlb_stale().store(true);
+  }
 }
 
 // TLB invalidation, then the handles go back to the pool / the driver. Touches no allocator state (the async
@@ -1555,7 +1659,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
 void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   if (!u.n) return;
   GpuContext *ctx = ctx_;
-  PhysPool *pool = ctx->pool(u.page_size, exportable_);
+  PiecePool *pool = ctx->pieces(u.page_size, exportable_);
   // Stale TLB entries still translate the unmapped VAs to the old physical pages. Who can be hurt by them?
   //   * a reader of the VA itself: only in compat mode is that legal (unbacked VA reads as zeros), so there the
   //     invalidation happens now;

@@ -34,6 +34,7 @@ struct Options {
   std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
   std::atomic<int64_t> hip_reg_group_mb{64};     // hybrid/drm: VA introduced to HIP per hipMemMap (0 = slot by slot)
   std::atomic<int64_t> clear_run_slots{16};      // drm backend: unmap runs of adjacent slots with one CLEAR ioctl (0 = off)
+  std::atomic<int64_t> phys_chunk_pages{1};      // drm backend: physical memory in chunks of this many pages (1 = off)
   std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
@@ -71,6 +72,9 @@ public:
   void bind() const; // hipSetDevice for the calling thread (HIP's current device is per thread)
   hipStream_t stream() const { return stream_; }
   PhysPool *pool(size_t granule, bool exportable);
+  // What map/unmap take pages from: page-sized pieces of chunks of KVCACHED_PHYS_CHUNK_PAGES pages (drm backend with
+  // pages straight from KFD, non-exportable pools), or - the default, k = 1 - a pass-through to pool().
+  PiecePool *pieces(size_t page_bytes, bool exportable);
   void drain_pools();
   size_t idle_pool_bytes(); // physical memory parked in the handle pools: ours to reuse, invisible to hipMemGetInfo
   // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
@@ -130,7 +134,8 @@ private:
   bool fl_stop_ = false, fl_kick_ = false;
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
-  std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2];
+  std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2]; // key: granule (chunk pools: granule + 1)
+  std::unordered_map<size_t, std::unique_ptr<PiecePool>> piece_pools_[2];
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
   // unique_block_ids scratch (grow-only; bitmap all-zero and header reset between calls)

@@ -285,6 +285,8 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
     the process (csrc/inc/gpu_vmm.hpp:37-45); here the batch is undone, alloc_page rolls the page id back
     (page_allocator.cpp:215-224 finally reachable), alloc() raises RuntimeError naming the page, and the very same
     allocation succeeds afterwards with the same block ids."""
+    if int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")) > 1:
+        pytest.skip("page-granular pool semantics; with chunked physical memory the fault-injection hook counts driver allocations, which are chunks then")
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
@@ -330,6 +332,8 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
 def test_shrinking_the_budget_releases_pooled_handles(monkeypatch):
     """`kvctl limit` semantics: a successful shrink gives memory back now — what the handle pool parked goes to the
     driver at once instead of waiting for the idle decay (the reference releases on every unmap)."""
+    if int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")) > 1:
+        pytest.skip("page-granular pool semantics; with chunked physical memory memory goes back to the driver by whole chunks then, and these 40 pages do not make up any")
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
