@@ -449,6 +449,8 @@ def main():
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (
+                        ("physical_chunks_32MiB_opt_in", "lazy", None, 0, False, True),
+                        ("physical_chunks_8MiB_opt_in", "lazy", None, 0, False, True),
                         ("unmap_waits_for_its_own_tlb_invalidation", "lazy", None, 0, False, True),
                         ("hybrid_backend_same_cycle", "lazy", None, 0, False, True),
                         ("hip_backend_same_cycle", "lazy", None, 0, False, True),
@@ -464,7 +466,9 @@ def main():
                     try:
                         if name.startswith("unmap_waits"):
                             os.environ["KVCACHED_ASYNC_SHOOTDOWN"] = "false"
-                        nsteps = 24 if (burst or name.startswith(("fresh_va", "unmap_waits")) or name.endswith("_backend_same_cycle")) else 8
+                        if name.startswith("physical_chunks"):   # KVCACHED_PHYS_CHUNK_PAGES: DESIGN.md §4.8
+                            os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = "16" if "32MiB" in name else "4"
+                        nsteps = 24 if (burst or name.startswith(("fresh_va", "unmap_waits", "physical_chunks")) or name.endswith("_backend_same_cycle")) else 8
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
                                      backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
                                      else ("hip" if name.startswith("hip_") else ("hybrid" if name.startswith("hybrid_") else args.backend)),
@@ -480,6 +484,7 @@ def main():
                         variants[name] = {"error": str(e)[:200]}
                     finally:
                         os.environ.pop("KVCACHED_ASYNC_SHOOTDOWN", None)
+                        os.environ.pop("KVCACHED_PHYS_CHUNK_PAGES", None)
                 line["variants"] = variants
                 try:
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)
