@@ -107,6 +107,8 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              pages are also allocated straight from KFD (AMDKFD_IOC_ALLOC_MEMORY_OF_GPU on the
  *                              library's own fd of /dev/kfd: 5 us flat instead of the runtime's O(live handles);
  *                              KVCACHED_DRM_KFD_CREATE=false keeps ROCr's creation; kvc_get_option(110) = 1 when active).
+ *                              KVCACHED_PHYS_CHUNK_PAGES=k (default 1) allocates that memory in chunks of k pages and
+ *                              maps runs of adjacent slots with one ioctl (opt-in).
  *                              DESIGN.md §4.6/§4.7.
  *   KVC_OPT_ASYNC_UNMAP    1 = kvc_unmap_from_kv_tensors only marks the slots and queues them; a reclaimer thread
  *                              of the library carries out hipMemUnmap + invalidation + handle recycling in small
