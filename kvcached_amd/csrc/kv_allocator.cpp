@@ -1644,7 +1644,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     }
   }
   flush_run();
-  if (!touched.empty()) {
+  if (!touched.empty() && !env_bool("KVCACHED_TEST_SKIP_REMAINDER_REFRESH", false)) { // hook: prove the test has teeth
     std::sort(touched.begin(), touched.end());
     touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
     for (auto c : touched)

@@ -266,6 +266,55 @@ def test_unmap_batches_with_runs_of_neighbours(vmm):
     assert st["handles_created"] == st["handles_released"]
 
 
+def test_chunked_physical_memory_opt_in(vmm, monkeypatch):
+    """KVCACHED_PHYS_CHUNK_PAGES=16: physical memory in 32 MiB chunks, page-sized pieces mapped at
+    offsets, runs of adjacent slots in one ioctl. The hazard this mode has to handle: pages taken out of the middle of a
+    multi-page mapping leave neighbours whose page-table entries still claim the old extent - a slot backed afresh
+    would show its previous page. Seeded churn over two regions with every slot stamped and checked, neighbours read
+    in between; then the ledger: whole chunks only, nothing leaked."""
+    import random
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "16")
+    ops, capi, ts = _setup(vmm, layers=2, per_layer=192 * MiB, backfill=False, kv=1, unified=False)
+    if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+        pytest.skip("needs the drm backend with pages straight from KFD")
+    capi.reset_stats()
+    n, epp = 96, PAGE // 2
+    rng = random.Random(11)
+    stamp = {}                                                        # slot -> value both layers carry
+    serial = 0
+
+    def check_all():
+        torch.cuda.synchronize()
+        for i, v in stamp.items():
+            for t in ts:
+                assert bool((t[i * epp:(i + 1) * epp] == v).all()), (i, v)
+
+    for rnd in range(12):
+        free = [i for i in range(n) if i not in stamp]
+        want = rng.sample(free, rng.randint(1, len(free)))
+        want.sort(key=lambda _: rng.random())
+        assert ops.map_to_kv_tensors([i * PAGE for i in want])         # one offset = the slot in BOTH layers
+        for i in want:
+            serial += 1
+            for t in ts:
+                assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0, (rnd, i)   # never a previous page
+                t[i * epp:(i + 1) * epp].fill_(serial)
+            stamp[i] = serial
+        check_all()
+        victims = rng.sample(sorted(stamp), rng.randint(1, max(1, len(stamp) * 2 // 3)))   # holes inside the runs
+        assert ops.unmap_from_kv_tensors([i * PAGE for i in victims])
+        for i in victims:
+            stamp.pop(i)
+        check_all()                                                    # the survivors, right after their mappings were split
+    st = capi.get_stats()
+    assert st["handles_created"] % 16 == 0 and st["handles_created"] >= 2 * 16       # counted in pages, made in chunks
+    assert st["handles_reused"] < st["pages_mapped"] <= st["handles_created"] + st["handles_reused"]
+    assert ops.unmap_from_kv_tensors([i * PAGE for i in sorted(stamp)])
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_reinit_never_writes_through_a_translation_of_a_previous_life(vmm):
     """Map batches no longer invalidate by themselves, so every path that removes a LIVE translation must: region
     teardown (pages and zero aliases), the init self tests, rollbacks. Otherwise: a region is torn down, its physical
