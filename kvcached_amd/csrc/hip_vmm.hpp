@@ -225,8 +225,8 @@ inline const HsaDevice &hsa_device(int hip_dev) {
 class DrmVm {
 public:
   static DrmVm &instance() {
-    static DrmVm v;
-    return v;
+    static DrmVm *v = new DrmVm; // never destroyed: GPU contexts that outlive main() (no shutdown call) still release through it
+    return *v;
   }
   bool ready() const { return dev_ != nullptr; }
   int hip_dev() const { return hip_dev_; }

@@ -36,8 +36,11 @@ void Stats::reset() {
 
 namespace {
 std::mutex g_mu; // guards the registry below
-std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> g_allocators;
-std::unordered_map<int, std::unique_ptr<GpuContext>> g_contexts;
+// Never destroyed: a process that ends without kvc_shutdown() must not tear GPU state down from static destructors -
+// the HIP runtime, ROCr and libdrm are going away in an unspecified order at that point (that crashed at exit); the
+// kernel reclaims mappings and memory with the process. The Python module shuts down in an atexit hook, in good time.
+auto &g_allocators = *new std::unordered_map<int64_t, std::unique_ptr<KvAllocator>>;
+auto &g_contexts = *new std::unordered_map<int, std::unique_ptr<GpuContext>>;
 DeviceSpec g_device;
 bool g_contiguous = false;
 bool g_initialized = false;

@@ -266,6 +266,36 @@ def test_unmap_batches_with_runs_of_neighbours(vmm):
     assert st["handles_created"] == st["handles_released"]
 
 
+_EXIT_CHILD = """
+import os, sys
+sys.path.insert(0, %r)
+os.environ["KVCACHED_IPC_NAME"] = "kvc_exit_%%d" %% os.getpid()
+import torch
+from kvcached_amd import vmm_ops
+vmm_ops.init_kvcached("cuda:0", 2 << 20, False)
+ts = vmm_ops.create_kv_tensors(64 << 20, 2, "cuda:0", 2, 2, 0, False)
+assert vmm_ops.map_to_kv_tensors([0, 2 << 20, 6 << 20])
+ts[0][:100].fill_(3)
+assert vmm_ops.unmap_from_kv_tensors([2 << 20])
+torch.cuda.synchronize()
+print("leaving without shutdown_kvcached", flush=True)
+"""
+
+
+@pytest.mark.parametrize("backend", ["drm", "hybrid", "hip"])
+def test_process_exit_without_shutdown_is_clean(backend):
+    """An engine that simply exits (no shutdown_kvcached) must not crash on the way out: nothing of the library tears
+    GPU state down from static destructors - the HIP runtime, ROCr and libdrm are going away in an unspecified order
+    then (that used to end in a segmentation fault); the kernel reclaims mappings and memory with the process."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVCACHED_VMM_BACKEND=backend, KVCACHED_LOG_LEVEL="ERROR")
+    r = subprocess.run([sys.executable, "-c", _EXIT_CHILD % repo], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stderr[-800:])
+    assert "leaving without shutdown_kvcached" in r.stdout
+
+
 def test_chunked_physical_memory_opt_in(vmm, monkeypatch):
     """KVCACHED_PHYS_CHUNK_PAGES=16: physical memory in 32 MiB chunks, page-sized pieces mapped at
     offsets, runs of adjacent slots in one ioctl. The hazard this mode has to handle: pages taken out of the middle of a
