@@ -282,6 +282,38 @@ print("leaving without shutdown_kvcached", flush=True)
 """
 
 
+_EXIT_CHILD_MANAGER = """
+import os, sys, time
+sys.path.insert(0, %r)
+os.environ["KVCACHED_IPC_NAME"] = "kvc_exitm_%%d" %% os.getpid()
+os.environ["KVCACHED_PAGE_PREALLOC_ENABLED"] = "true"
+import torch
+import kvcached_amd.kv_cache_manager as kcm
+from kvcached_amd import vmm_ops
+vmm_ops.init_kvcached("cuda:0", 2 << 20, False)
+vmm_ops.create_kv_tensors(64 * (2 << 20) * 2, 1, "cuda:0", 2, 2, 0, False)
+m = kcm.KVCacheManager(num_blocks=64 * 64, block_size=16, cell_size=2048, num_layers=2)
+assert m._post_init_done.wait(20)
+ids = m.alloc(20 * 64)
+m.free(ids[:600])
+time.sleep(0.25)          # prealloc + watcher threads are running, pages are mapped, an invalidation may be in flight
+print("leaving with a live manager", flush=True)
+"""
+
+
+def test_process_exit_with_a_live_manager_is_clean():
+    """... and neither must its threads: an engine exits with a KVCacheManager alive (prealloc thread, 10 Hz watcher,
+    the context's invalidation thread), pages mapped and blocks allocated."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVCACHED_LOG_LEVEL="ERROR")
+    env.pop("KVCACHED_VMM_BACKEND", None)
+    r = subprocess.run([sys.executable, "-c", _EXIT_CHILD_MANAGER % repo], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stderr[-800:])
+    assert "leaving with a live manager" in r.stdout
+
+
 @pytest.mark.parametrize("backend", ["drm", "hybrid", "hip"])
 def test_process_exit_without_shutdown_is_clean(backend):
     """An engine that simply exits (no shutdown_kvcached) must not crash on the way out: nothing of the library tears
