@@ -982,9 +982,27 @@ public:
         return want;
       }
     }
+    // No partly used chunk has `want` neighbours free. A whole idle chunk costs nothing new; failing that, whatever
+    // free pieces exist are used up - a shorter run now, the caller comes back for the rest - BEFORE a new chunk is
+    // made: physical memory allocated never exceeds what is mapped by more than one chunk's worth of pieces
+    // (opening a chunk per run tripled the footprint of the Poisson workload).
     Phys c;
     bool rec = true;
     if (!chunks_->try_acquire_idle(&c)) {
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!partial_.empty()) {
+          const phys_handle_t h = *partial_.begin();
+          Chunk &pc = tracked_[h];
+          unsigned n = (unsigned)want;
+          int first = -1;
+          while (n >= 1 && (first = find_run(pc.free_mask, n)) < 0) --n; // the longest run this chunk still has, up to `want`
+          const unsigned old = take(h, pc, (unsigned)first, n, out);
+          *recycled = old > 0;
+          ctr_->reused += old;
+          return n;
+        }
+      }
       if (!may_create) return 0;
       c = chunks_->acquire(&rec); // may throw: nothing of ours has changed yet
     }
@@ -993,6 +1011,7 @@ public:
     t.seq = c.seq;
     t.free_mask = full_;
     t.used_mask = rec ? full_ : 0; // a chunk from the idle pool has been used all over, a new one nowhere
+    free_pieces_ += k_;
     const unsigned old = take(c.h, t, 0, (unsigned)want, out);
     *recycled = old > 0;
     ctr_->reused += old;
@@ -1017,7 +1036,9 @@ public:
           continue;
         }
         it->second.free_mask |= 1ull << piece_of(ps[i].h);
+        ++free_pieces_;
         if (it->second.free_mask == full_) {
+          free_pieces_ -= k_; // the chunk goes back whole: counted by the chunk pool from here on
           whole.push_back(Phys{h, it->second.seq});
           partial_.erase(h);
           tracked_.erase(it);
@@ -1032,9 +1053,7 @@ public:
   size_t free_piece_bytes() {
     if (k_ == 1) return 0;
     std::lock_guard<std::mutex> g(mu_);
-    size_t n = 0;
-    for (auto h : partial_) n += (size_t)__builtin_popcountll(tracked_[h].free_mask);
-    return n * piece_bytes_;
+    return free_pieces_ * piece_bytes_;
   }
 
 private:
@@ -1055,6 +1074,7 @@ private:
     for (unsigned i = 0; i < n; ++i) {
       const uint64_t bit = 1ull << (first + i);
       c.free_mask &= ~bit;
+      --free_pieces_;
       old += (c.used_mask & bit) != 0;
       c.used_mask |= bit;
       out[i] = Phys{piece_id(h, first + i), c.seq};
@@ -1071,6 +1091,7 @@ private:
   VmmCounters *ctr_;
   uint64_t full_;
   std::mutex mu_;
+  size_t free_pieces_ = 0;                            // free pieces inside tracked chunks
   std::unordered_map<phys_handle_t, Chunk> tracked_; // chunks with at least one piece handed out
   std::set<phys_handle_t> partial_;                   // ... of which some pieces are free
 };
