@@ -116,7 +116,17 @@ def main():
 
     t_end = time.time() + args.seconds
     shrunk = False
+    slots_per_page_id = LAYERS * 2
+    footprint = []                                              # (pages held from the driver) / (pages mapped), sampled
+    n_ops = 0
     while time.time() < t_end and not bad:
+        n_ops += 1
+        if n_ops % 64 == 0:
+            st_now = capi.get_stats()
+            held_pages = st_now["handles_created"] - st_now["handles_released"]
+            mapped_pages = (m.page_allocator.get_num_inuse_pages() + m.page_allocator.get_num_reserved_pages()) * slots_per_page_id
+            if mapped_pages >= 256:
+                footprint.append(held_pages / mapped_pages)
         r = rng.random()
         held = sum(len(v[1]) for v in live.values())
         if r < 0.50 or not live:
@@ -161,7 +171,11 @@ def main():
     vmm_ops.shutdown_kvcached()
     end = capi.get_stats()
     leak = end["handles_created"] - end["handles_released"]
-    out = dict(backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
+    fp = sorted(footprint) or [0.0]
+    out = dict(held_over_mapped={"p50": round(fp[len(fp) // 2], 3), "p90": round(fp[int(len(fp) * 0.9)], 3), "max": round(fp[-1], 3),
+                                 "what": "physical pages held from the driver (mapped + pooled + free pieces of partly used chunks) per mapped page"},
+               chunk_pages=int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")),
+               backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
                prealloc=args.prealloc, **counts, wrong_words=bad, inuse_pages_at_end=inuse,
                pages_mapped=st["pages_mapped"], pages_unmapped=st["pages_unmapped"],
                handles_created=end["handles_created"], handles_reused=end["handles_reused"], handle_leak=leak)
