@@ -119,8 +119,13 @@ def main():
     slots_per_page_id = LAYERS * 2
     footprint = []                                              # (pages held from the driver) / (pages mapped), sampled
     n_ops = 0
+    t_progress = time.time()
     while time.time() < t_end and not bad:
         n_ops += 1
+        if time.time() - t_progress > 30:                       # a line every 30 s: long runs must not look hung
+            t_progress = time.time()
+            print(f"[soak] {int(t_end - time.time())} s to go, {counts['alloc']} allocs, {counts['blocks_verified']} blocks verified, "
+                  f"{bad} wrong words", file=sys.stderr, flush=True)
         if n_ops % 64 == 0:
             st_now = capi.get_stats()
             held_pages = st_now["handles_created"] - st_now["handles_released"]
