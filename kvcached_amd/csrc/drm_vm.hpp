@@ -280,6 +280,7 @@ private:
   }
   static uint32_t kfd_gpu_id_for(unsigned domain, unsigned bus, unsigned dev, unsigned fn) {
     const unsigned long long want = (bus << 8) | (dev << 3) | fn;
+    uint32_t found = 0;
     for (int n = 0; n < 256; n++) {
       char path[128];
       snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
@@ -298,9 +299,12 @@ private:
         if (!strcmp(key, "domain")) dom = val;
       }
       fclose(f);
-      if (loc == want && dom == domain) return (uint32_t)id;
+      if (loc == want && dom == domain) {
+        if (found) return 0; // several KFD nodes behind one PCI address (a partitioned GPU): do not guess
+        found = (uint32_t)id;
+      }
     }
-    return 0;
+    return found;
   }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
   static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR
@@ -336,6 +340,7 @@ private:
   }
   static std::string render_node_for(const char *bdf) {
     std::string found;
+    bool ambiguous = false;
     DIR *d = opendir("/sys/class/drm");
     if (!d) return found;
     while (dirent *e = readdir(d)) {
@@ -344,9 +349,13 @@ private:
       snprintf(link, sizeof link, "/sys/class/drm/%s/device", e->d_name);
       if (!realpath(link, real)) continue;
       const char *leaf = strrchr(real, '/');
-      if (leaf && strcasecmp(leaf + 1, bdf) == 0) found = std::string("/dev/dri/") + e->d_name;
+      if (leaf && strcasecmp(leaf + 1, bdf) == 0) {
+        if (!found.empty()) ambiguous = true; // several render nodes behind one PCI address (a partitioned GPU)
+        found = std::string("/dev/dri/") + e->d_name;
+      }
     }
     closedir(d);
+    if (ambiguous) found.clear(); // do not guess: the caller falls back to the hybrid backend
     return found;
   }
   void close_locked() {
