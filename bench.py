@@ -371,8 +371,53 @@ def ensure_built(local_rank: int) -> None:
     time.sleep(2.0)  # let the linker finish writing
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher. It starts N copies of this
+    script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run
+    would set them - the reference's harness spawns its ranks itself too,
+    benchmarks/bench_tp_ipc/kvcached_tp_ipc_benchmark.py:131,212), relays rank 0's JSON line and returns the worst
+    exit status. The launcher never imports torch and never touches HIP (nothing that has initialised the GPU is
+    replaced or forked), and the children are plain child processes, not an exec of this one."""
+    import socket
+    ensure_built(0)   # once, before the ranks start (a subprocess; no GPU involved)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as rank0_out:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_{os.getpid()}_r{r}")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=rank0_out if r == 0 else sys.stderr))
+        failed = None
+        while any(p.poll() is None for p in procs):
+            failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+            if failed is not None:   # the others would wait for it in a collective for ever: end exactly those processes
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.1)
+        rcs = [p.wait() for p in procs]
+        if failed is not None:
+            print(f"bench.py: rank {procs.index(failed)} exited with status {failed.returncode}; the other ranks were stopped",
+                  file=sys.stderr)
+            return failed.returncode if failed.returncode > 0 else 1
+        rank0_out.seek(0)
+        sys.stdout.write(rank0_out.read())
+        sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return (bad[0] if bad[0] > 0 else 1) if bad else 0
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     ensure_built(int(os.environ.get("LOCAL_RANK", "0")))
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -380,18 +425,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    if not torch.cuda.is_available():
+    # Rehearsal of the launcher / fan-out / JSON contract without a GPU (tests only, KVC_BENCH_REHEARSAL=cpu): the
+    # library's "cpu" device keeps the books and maps nothing, so the line it prints is labelled as no measurement.
+    rehearsal = os.environ.get("KVC_BENCH_REHEARSAL") == "cpu"
+    if os.environ.get("KVC_BENCH_TEST_FAIL_RANK") == str(rank):   # tests: a rank that dies before the rendezvous
+        sys.exit(7)
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_{os.getpid()}")
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
-    local_rank %= max(1, torch.cuda.device_count())   # rehearsals may put several ranks on one GPU
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    if rehearsal:
+        device = "cpu"
+    else:
+        n_dev = torch.cuda.device_count()
+        if world > n_dev and os.environ.get("KVC_BENCH_SHARE_GPUS") != "1":
+            raise SystemExit(f"bench.py: {world} ranks but only {n_dev} GPUs visible (KVC_BENCH_SHARE_GPUS=1 puts several "
+                             "ranks on one GPU for a rehearsal; its numbers are not a scaling measurement)")
+        local_rank %= max(1, n_dev)
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
     from kvcached_amd import capi
 
     fanout = barrier = None
-    sync = torch.cuda.synchronize
-    backend = os.environ.get("KVC_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N>1 code path on one GPU
+    sync = None if rehearsal else torch.cuda.synchronize
+    backend = "gloo" if rehearsal else os.environ.get("KVC_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N>1 code path
+    ranks_seen = [rank]
     use_dist = world > 1 or os.environ.get("KVC_BENCH_FORCE_DIST") == "1"   # forced: rehearse the N>1 path on one GPU
     if use_dist:
         import torch.distributed as dist
@@ -412,6 +470,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         res["elapsed"] = elapsed
+        # who took part, and how many pages each rank really backed inside the timed region (value = their sum / max time)
+        mine = torch.tensor([rank, res["stats"]["pages_mapped"]], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        ranks_seen = sorted(int(e[0]) for e in everyone)
+        pages_by_rank = [int(e[1]) for e in sorted(everyone, key=lambda e: int(e[0]))]
+        assert all(p == pages_by_rank[0] for p in pages_by_rank), f"ranks backed different amounts: {pages_by_rank}"
     main_sum = summarize(res, args.steps, world)
 
     if rank == 0:
@@ -427,11 +492,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "REHEARSAL on the library's cpu device: bookkeeping only, nothing is mapped - not a measurement",
+            "ranks": ranks_seen,
             "config": {"workload": "bench_vmm: 64 GiB VA window (one untimed warm-up sweep over the window during set-up, as in "
                                    "the protocol); step = map+zero then unmap one batch of 1024 x 2 MiB "
                                    "pages (shuffled offsets), both halves timed",
-                       "mode": args.mode, "vmm_backend": res["backend_in_effect"], "vmm_backend_requested": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
+                       "mode": args.mode, "vmm_backend": res["backend_in_effect"] if not rehearsal else "none (cpu device)", "vmm_backend_requested": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
             "map_zero_GBps": round(main_sum["map_zero_GBps"], 2),
@@ -445,7 +511,7 @@ def main():
             "driver_us_per_page": main_sum["driver_us_per_page"], "tlb_shootdown_us": main_sum["tlb_shootdown_us"],
             "roofline": roofline_from(res["stats"]),
         }
-        if world == 1:
+        if world == 1 and not rehearsal:
             if not args.no_variants:
                 variants = {}
                 for name, mode, pool, comp, burst, pre in (

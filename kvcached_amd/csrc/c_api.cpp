@@ -152,6 +152,12 @@ int64_t kvc_get_option(int opt) {
   case 108: return vmm_backend().load(); // effective VMM backend: 0 hip, 1 hsa, 2 hybrid, 3 drm (read-only)
   case 111: return background_shootdowns().load(); // TLB invalidations done by the library's own threads (read-only)
   case 110: return vmm_backend().load() == kVmmDrm && DrmVm::instance().kfd_ready() ? 1 : 0; // physical pages straight from KFD (read-only)
+  case 112: return DrmVm::instance().create_times().alloc_ns.load();  // KFD allocation ioctls, ns (read-only, 112-117)
+  case 113: return DrmVm::instance().create_times().export_ns.load(); // dmabuf exports
+  case 114: return DrmVm::instance().create_times().import_ns.load(); // imports into DRM
+  case 115: return DrmVm::instance().create_times().count.load();
+  case 116: return DrmVm::instance().create_times().free_ns.load();   // DRM + KFD frees
+  case 117: return DrmVm::instance().create_times().frees.load();
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;

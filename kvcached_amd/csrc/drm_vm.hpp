@@ -94,10 +94,13 @@ public:
       e = it->second;
       bo_.erase(it);
     }
+    const int64_t t0 = now_ns();
     (void)api_.bo_free(e.bo);
     if (!e.kfd) return false;
     KfdFree f{h};
     if (kfd_ioctl(kKfdFree, &f) != 0) KVC_LOG(LOG_ERROR, "AMDKFD_IOC_FREE_MEMORY_OF_GPU failed: %s", strerror(errno));
+    create_times_.free_ns += now_ns() - t0;
+    create_times_.frees++;
     return true;
   }
 
@@ -135,24 +138,37 @@ public:
     return true;
   }
   // One buffer of `size` bytes of this GPU's memory, imported into DRM: {handle, bo}. Throws GpuError.
+  // Where a creation's time goes (ns sums since the process started; kvc_get_option 112-115): the KFD allocation, the
+  // dmabuf export, the import into DRM (+ close of the fd).
+  struct CreateTimes {
+    std::atomic<int64_t> alloc_ns{0}, export_ns{0}, import_ns{0}, count{0}, free_ns{0}, frees{0};
+  };
+  CreateTimes &create_times() { return create_times_; }
   phys_handle_t create(size_t size) {
     KfdAlloc a{};
     a.size = size;
     a.gpu_id = gpu_id_;
     a.flags = kKfdVramFlags;
+    const int64_t t0 = now_ns();
     if (kfd_ioctl(kKfdAlloc, &a) != 0)
       throw GpuError(std::string("AMDKFD_IOC_ALLOC_MEMORY_OF_GPU failed: ") + (errno == ENOMEM ? "out of memory" : strerror(errno)));
+    const int64_t t1 = now_ns();
     KfdExport e{};
     e.handle = a.handle;
     e.flags = O_CLOEXEC | O_RDWR;
     ImportResult res{};
     int r = kfd_ioctl(kKfdExport, &e) != 0 ? -errno : 0;
+    const int64_t t2 = now_ns();
     if (r == 0) {
       std::lock_guard<std::mutex> g(mu_);
       r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, e.dmabuf_fd, &res) : -ENODEV;
       ::close((int)e.dmabuf_fd);
       if (r == 0 && res.bo) bo_[a.handle] = Entry{res.bo, true};
     }
+    create_times_.alloc_ns += t1 - t0;
+    create_times_.export_ns += t2 - t1;
+    create_times_.import_ns += now_ns() - t2;
+    create_times_.count++;
     if (r != 0 || !res.bo) {
       KfdFree f{a.handle};
       (void)kfd_ioctl(kKfdFree, &f);
@@ -384,6 +400,7 @@ private:
   int kfd_fd_ = -1;      // our own open of /dev/kfd (same kfd_process as ROCr's)
   uint32_t gpu_id_ = 0;  // KFD's id of the device
   std::unordered_map<phys_handle_t, Entry> bo_; // ROCr handle or KFD handle -> buffer object
+  CreateTimes create_times_;
   std::mutex scratch_mu_;
   void *scratch_va_ = nullptr; // one page of reserved VA for refresh_mappings_of()
   size_t scratch_bytes_ = 0;
