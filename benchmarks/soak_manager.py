@@ -47,7 +47,7 @@ def main():
     dev = "cuda:0"
     torch.cuda.set_device(0)
     vmm_ops.init_kvcached(dev, PAGE, False)
-    backend = {0: "hip", 1: "hsa", 2: "hybrid", 3: "drm"}[capi.get_option(108)]
+    backend = {0: "hip", 2: "hybrid", 3: "drm"}[capi.get_option(108)]
     blocks_per_page = PAGE // BLOCK_BYTES
     num_blocks = args.page_ids * blocks_per_page
     per_layer = num_blocks * BLOCK_BYTES * 2                   # K half + V half

@@ -47,7 +47,7 @@ def build_lib(force: bool = False) -> str:
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-Wall", "-Wno-unused-result", "-x", "hip"]
         cmd += [os.path.join(CSRC, s) for s in LIB_SRCS]
-        cmd += ["-o", LIB, f"-L{os.path.join(ROCM, 'lib')}", "-lhsa-runtime64", "-ldl"]  # ROCr directly (hybrid/drm/hsa VMM backends); libdrm_amdgpu is dlopen()ed
+        cmd += ["-o", LIB, f"-L{os.path.join(ROCM, 'lib')}", "-lhsa-runtime64", "-ldl"]  # ROCr directly (hybrid/drm VMM backends); libdrm_amdgpu is dlopen()ed
         _run(cmd)
     return LIB
 

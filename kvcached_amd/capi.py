@@ -25,10 +25,15 @@ KVC_E_NOT_CREATED = -7
 OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN, OPT_DEFER_UNMAP_SHOOTDOWN = 1, 2, 3, 4, 5, 6
 OPT_ASYNC_UNMAP = 7
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
-# read-only: the VMM backend in effect after init's self tests (0 hip, 1 hsa, 2 hybrid, 3 drm), and whether physical
+# read-only: the VMM backend in effect after init's self tests (0 hip, 2 hybrid, 3 drm), and whether physical
 # pages come straight from KFD (drm backend only)
 OPT_EFFECTIVE_BACKEND, OPT_KFD_CREATE_ACTIVE = 108, 110
 OPT_BACKGROUND_SHOOTDOWNS = 111  # read-only: TLB invalidations performed by the library's own threads so far
+# read-only: 112-117 KFD allocation / dmabuf export / DRM import ns, creations, free ns, frees; 118 the direct KFD TLB flush
+# is in use; 119 pages per physical extent at most; 120-123 pool footprint: pages held from the driver, pages handed out,
+# free pieces inside partly used extents (the waste), the extent size new runs get right now
+OPT_KFD_TLB_FLUSH_ACTIVE, OPT_MAX_EXTENT_PAGES = 118, 119
+OPT_POOL_HELD_PAGES, OPT_POOL_OUT_PAGES, OPT_POOL_FREE_PIECES, OPT_POOL_EXTENT_PAGES_NOW = 120, 121, 122, 123
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _I64P = ctypes.POINTER(ctypes.c_int64)

@@ -149,7 +149,7 @@ int64_t kvc_get_option(int opt) {
   case 105: return options().fill_chunk_slots;
   case 107: return options().pool_idle_ms;
   case 109: return options().async_shootdown;
-  case 108: return vmm_backend().load(); // effective VMM backend: 0 hip, 1 hsa, 2 hybrid, 3 drm (read-only)
+  case 108: return vmm_backend().load(); // effective VMM backend: 0 hip, 2 hybrid, 3 drm (read-only)
   case 111: return background_shootdowns().load(); // TLB invalidations done by the library's own threads (read-only)
   case 110: return vmm_backend().load() == kVmmDrm && DrmVm::instance().kfd_ready() ? 1 : 0; // physical pages straight from KFD (read-only)
   case 112: return DrmVm::instance().create_times().alloc_ns.load();  // KFD allocation ioctls, ns (read-only, 112-117)
@@ -158,6 +158,27 @@ int64_t kvc_get_option(int opt) {
   case 115: return DrmVm::instance().create_times().count.load();
   case 116: return DrmVm::instance().create_times().free_ns.load();   // DRM + KFD frees
   case 117: return DrmVm::instance().create_times().frees.load();
+  case 118: { // the direct KFD TLB flush is what tlb_shootdown() uses (read-only)
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx && ctx->kfd_flush_active() ? 1 : 0;
+  }
+  case 119: return options().phys_chunk_pages; // pages per extent at most (read-only; KVCACHED_PHYS_CHUNK_PAGES at init)
+  case 120: { // pool footprint: pages held from the driver (read-only, 120-123)
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().held_pages : 0;
+  }
+  case 121: {
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().out_pages : 0;
+  }
+  case 122: {
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().free_pieces : 0;
+  }
+  case 123: {
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().extent_pages_now : 0;
+  }
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;

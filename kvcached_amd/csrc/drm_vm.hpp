@@ -5,6 +5,145 @@
 
 namespace kvc {
 
+// KFD's id of the device behind a PCI address (sysfs topology); 0: not found, or several KFD nodes behind one address
+// (a partitioned GPU): never guess.
+inline uint32_t kfd_gpu_id_for(unsigned domain, unsigned bus, unsigned dev, unsigned fn) {
+  const unsigned long long want = (bus << 8) | (dev << 3) | fn;
+  uint32_t found = 0;
+  for (int n = 0; n < 256; n++) {
+    char path[128];
+    snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
+    FILE *f = fopen(path, "r");
+    if (!f) break;
+    unsigned long id = 0;
+    if (fscanf(f, "%lu", &id) != 1) id = 0;
+    fclose(f);
+    if (!id) continue; // a CPU node
+    snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+    if (!(f = fopen(path, "r"))) continue;
+    char key[64];
+    unsigned long long val, loc = ~0ull, dom = 0;
+    while (fscanf(f, "%63s %llu", key, &val) == 2) {
+      if (!strcmp(key, "location_id")) loc = val;
+      if (!strcmp(key, "domain")) dom = val;
+    }
+    fclose(f);
+    if (loc == want && dom == domain) {
+      if (found) return 0;
+      found = (uint32_t)id;
+    }
+  }
+  return found;
+}
+inline uint32_t kfd_gpu_id_of_hip_device(int hip_dev) {
+  char bdf[64] = {0};
+  unsigned dom = 0, bus = 0, dv = 0, fn = 0;
+  if (hipDeviceGetPCIBusId(bdf, sizeof bdf, hip_dev) != hipSuccess || sscanf(bdf, "%x:%x:%x.%x", &dom, &bus, &dv, &fn) != 4) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return kfd_gpu_id_for(dom, bus, dv, fn);
+}
+
+// ---- KfdTlbFlush: make the kernel invalidate this GPU's TLBs for our process - deterministically.
+// ROCm's VMM calls (HIP's, ROCr's, DRM's GEM_VA) leave stale translations behind; what flushes is KFD's
+// unmap path (kfd_ioctl_unmap_memory_from_gpu ends in a heavyweight flush of the process's VM on that GPU). Round 1
+// reached it through hipMalloc(2 MiB) + hipFree and watched the clock to guess whether the runtime had served the block
+// from a cache. This is the ioctl pair itself, on a 4 KiB buffer of our own at a VA nothing else will ever use, on our
+// own fd of /dev/kfd (every open of /dev/kfd by a process attaches to the same kfd_process, so it is ROCr's address
+// space): AMDKFD_IOC_MAP_MEMORY_TO_GPU + AMDKFD_IOC_UNMAP_MEMORY_FROM_GPU. No user-space cache can answer it; it costs
+// what the flush costs (170-200 us, tools/drm_vmm_probe.cpp mode 1: 0 wrong words where no flush gives all wrong).
+class KfdTlbFlush {
+public:
+  KfdTlbFlush() = default;
+  KfdTlbFlush(const KfdTlbFlush &) = delete;
+  ~KfdTlbFlush() { close(); }
+  bool ready() const { return handle_ != 0; }
+  bool open(int hip_dev, std::string *why) {
+    if (ready()) return true;
+    gpu_id_ = kfd_gpu_id_of_hip_device(hip_dev);
+    if (!gpu_id_) {
+      *why = "no single KFD topology node for the device";
+      return false;
+    }
+    fd_ = ::open("/dev/kfd", O_RDWR | O_CLOEXEC);
+    if (fd_ < 0) {
+      *why = std::string("cannot open /dev/kfd: ") + strerror(errno);
+      return false;
+    }
+    if (hipMemAddressReserve(&va_, kVaBytes, kVaBytes, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      *why = "no VA for the flush buffer";
+      close();
+      return false;
+    }
+    Alloc a{};
+    a.va_addr = reinterpret_cast<uint64_t>(va_);
+    a.size = 4096;
+    a.gpu_id = gpu_id_;
+    a.flags = (1u << 31) | (1u << 28) | 1u; // VRAM | WRITABLE | NO_SUBSTITUTE
+    if (call(kAlloc, &a) != 0) {
+      *why = std::string("AMDKFD_IOC_ALLOC_MEMORY_OF_GPU for the flush buffer: ") + strerror(errno);
+      close();
+      return false;
+    }
+    handle_ = a.handle;
+    if (!flush()) { // once, so that a kernel that refuses the pair is found out now
+      *why = std::string("AMDKFD_IOC_MAP/UNMAP_MEMORY of the flush buffer: ") + strerror(errno);
+      close();
+      return false;
+    }
+    return true;
+  }
+  bool flush() {
+    if (!ready()) return false;
+    Map m{handle_, reinterpret_cast<uint64_t>(&gpu_id_), 1, 0};
+    if (call(kMap, &m) != 0) return false;
+    m.n_success = 0;
+    return call(kUnmap, &m) == 0; // returns after the flush
+  }
+  void close() {
+    if (handle_) {
+      Free f{handle_};
+      (void)call(kFree, &f);
+      handle_ = 0;
+    }
+    if (va_) {
+      (void)hipMemAddressFree(va_, kVaBytes);
+      (void)hipGetLastError();
+      va_ = nullptr;
+    }
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
+  }
+
+private:
+  struct Alloc { // kfd_ioctl_alloc_memory_of_gpu_args
+    uint64_t va_addr, size, handle, mmap_offset;
+    uint32_t gpu_id, flags;
+  };
+  struct Free {
+    uint64_t handle;
+  };
+  struct Map { // kfd_ioctl_map_memory_to_gpu_args / unmap
+    uint64_t handle, device_ids_array_ptr;
+    uint32_t n_devices, n_success;
+  };
+  static constexpr unsigned long kAlloc = _IOWR('K', 0x16, Alloc), kFree = _IOW('K', 0x17, Free), kMap = _IOWR('K', 0x18, Map),
+                                 kUnmap = _IOWR('K', 0x19, Map);
+  static constexpr size_t kVaBytes = 2u << 20;
+  int call(unsigned long req, void *arg) {
+    int r;
+    do r = (int)syscall(SYS_ioctl, fd_, req, arg);
+    while (r == -1 && (errno == EINTR || errno == EAGAIN));
+    return r;
+  }
+  int fd_ = -1;
+  uint32_t gpu_id_ = 0;
+  void *va_ = nullptr;
+  uint64_t handle_ = 0;
+};
+
 // ---- DrmVm: the process's GPU address space, driven through libdrm_amdgpu directly.
 // What ROCr does per hsa_amd_vmem_map / set_access / unmap (tools/ioctl_timer.c, profiles/r01_unmap_trace_ioctls.log):
 // export the handle from KFD as a dmabuf, import it into DRM, query it, mmap; export and import AGAIN, then the one
@@ -293,34 +432,6 @@ private:
     do r = (int)syscall(SYS_ioctl, kfd_fd_, req, arg);
     while (r == -1 && (errno == EINTR || errno == EAGAIN)); // as the thunk does
     return r;
-  }
-  static uint32_t kfd_gpu_id_for(unsigned domain, unsigned bus, unsigned dev, unsigned fn) {
-    const unsigned long long want = (bus << 8) | (dev << 3) | fn;
-    uint32_t found = 0;
-    for (int n = 0; n < 256; n++) {
-      char path[128];
-      snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", n);
-      FILE *f = fopen(path, "r");
-      if (!f) break;
-      unsigned long id = 0;
-      if (fscanf(f, "%lu", &id) != 1) id = 0;
-      fclose(f);
-      if (!id) continue; // a CPU node
-      snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
-      if (!(f = fopen(path, "r"))) continue;
-      char key[64];
-      unsigned long long val, loc = ~0ull, dom = 0;
-      while (fscanf(f, "%63s %llu", key, &val) == 2) {
-        if (!strcmp(key, "location_id")) loc = val;
-        if (!strcmp(key, "domain")) dom = val;
-      }
-      fclose(f);
-      if (loc == want && dom == domain) {
-        if (found) return 0; // several KFD nodes behind one PCI address (a partitioned GPU): do not guess
-        found = (uint32_t)id;
-      }
-    }
-    return found;
   }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
   static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR

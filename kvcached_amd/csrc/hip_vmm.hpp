@@ -2,7 +2,7 @@
 //
 // Two APIs reach the same driver: HIP's (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess /
 // hipMemUnmap / hipMemRelease) and ROCr's (hsa_amd_vmem_*), which HIP sits on. Every verb below exists in both
-// forms; KVCACHED_VMM_BACKEND picks the combination (drm, hybrid, hip, hsa - see the comment above vmm_backend()).
+// forms; KVCACHED_VMM_BACKEND picks the combination (drm, hybrid, hip - see the comment above vmm_backend()).
 // No CUDA branch anywhere (the reference's csrc/inc/gpu_vmm.hpp is a CUDA/HIP dual shim - this is not).
 // Measured costs on MI355X / ROCm 7.2 that shaped the design (profiles/r01_*), per 2 MiB mapping:
 //   HIP : create 3.4 us | map 3.1 us | set_access 3.3 us | unmap 12-15 us (10 of them a GPU-marker spin) | release 3-50 us
@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "extent_pool.hpp"
 
 namespace kvc {
 
@@ -71,20 +72,9 @@ inline void hip_check(hipError_t st, const char *tok, const char *file, int line
 // (tools/hsa_vmm_probe.cpp, same box). The price: HIP never learns about such mappings. Kernels (raw pointers),
 // device-to-device hipMemcpy, hipMemset and hipPointerGetAttributes work on them; a host<->device hipMemcpy takes
 // the pointer for pageable host memory and crashes. Hence the hybrid backend (slots registered with HIP once, every
-// torch operation works on the KV tensors) and, on top of it, the default drm backend (DrmVm below);
-// KVCACHED_VMM_BACKEND=hsa is for engines that touch KV memory from kernels only, =hip is HIP's API alone.
-using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer), hsa_amd_vmem_alloc_handle_t::handle, or
-                                // (drm backend, pages allocated straight from KFD) KFD's buffer handle
-
-// Piece ids (drm backend, KVCACHED_PHYS_CHUNK_PAGES > 1): physical memory is allocated in chunks of k pages and a
-// handle names ONE page-sized piece of a chunk: the chunk's buffer handle (KFD handles are < 2^48) with the piece index
-// in the top byte. With k = 1 - every other backend, and the default - a piece id IS the handle.
-constexpr int kPieceShift = 56;
-inline phys_handle_t piece_id(phys_handle_t chunk, unsigned piece) { return chunk | (static_cast<uint64_t>(piece) << kPieceShift); }
-inline phys_handle_t chunk_of(phys_handle_t h) { return h & ((1ull << kPieceShift) - 1); }
-inline unsigned piece_of(phys_handle_t h) { return static_cast<unsigned>(h >> kPieceShift); }
-
-enum : int { kVmmHip = 0, kVmmHsa = 1, kVmmHybrid = 2, kVmmDrm = 3 };
+// torch operation works on the KV tensors) and, on top of it, the default drm backend (DrmVm below); =hip is HIP's API
+// alone, the last resort of the fallback chain.
+enum : int { kVmmHip = 0, kVmmHybrid = 2, kVmmDrm = 3 }; // (1 was a ROCr-only backend, dropped: HIP copies crashed on its memory)
 // kVmmHybrid: VA reserved through HIP and every slot registered with HIP once (hipMemMap of a placeholder handle,
 // taken away again through ROCr at once); from then on the slot is backed and unbacked with hsa_amd_vmem_* only.
 // HIP keeps resolving the pointer (its copies use the VA, the hardware walks the page tables ROCr wrote): every
@@ -125,14 +115,6 @@ struct HsaDevice {
   hsa_agent_t cpu{}; // a host agent, for mappings that HIP's host-side copy fallback may dereference
   bool have_cpu = false;
 };
-// hsa backend only. true (default): every mapping is also made accessible to the CPU agent. HIP, which takes a
-// pointer it has never seen for host memory, then really can read and write it (through the PCIe BAR: host->device
-// 11 GB/s, device->host 24 MB/s, coherent in tools/hsa_vmm_probe.cpp) instead of crashing. Costs 2.6 us per mapping
-// (set_access 3.1 -> 4.1, unmap 2.8 -> 4.4). false: kernels only.
-inline std::atomic<int> &hsa_cpu_access() {
-  static std::atomic<int> v{1};
-  return v;
-}
 inline const HsaDevice &hsa_device(int hip_dev) {
   static std::mutex mu;
   static std::unordered_map<int, HsaDevice> cache;
@@ -234,14 +216,10 @@ inline hsa_amd_vmem_alloc_handle_t as_hsa(phys_handle_t h) { return hsa_amd_vmem
 // ---- the VMM verbs, in a throwing form (vmm_*) and a quiet one for cleanup / rollback paths (vmm_try_*)
 inline void *vmm_reserve(size_t size, size_t align, void *hint) {
   void *p = nullptr;
-  if (vmm_backend() == kVmmHsa) // hybrid: through HIP, so that HIP knows the range
-    HSA_CHECK(hsa_amd_vmem_address_reserve_align(&p, size, reinterpret_cast<uint64_t>(hint), align, 0));
-  else
-    HIP_CHECK(hipMemAddressReserve(&p, size, align, hint, 0));
+  HIP_CHECK(hipMemAddressReserve(&p, size, align, hint, 0)); // always through HIP, so that HIP knows the range
   return p;
 }
 inline bool vmm_try_address_free(void *va, size_t size) {
-  if (vmm_backend() == kVmmHsa) return hsa_amd_vmem_address_free(va, size) == HSA_STATUS_SUCCESS;
   return hipMemAddressFree(va, size) == hipSuccess;
 }
 // `direct`: with the drm backend, also import the handle into DRM so that vmm_map/vmm_unmap take the one-ioctl path
@@ -297,8 +275,8 @@ inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
 inline void vmm_set_access(void *va, size_t size, int dev) {
   if (vmm_uses_rocr()) {
     const HsaDevice &hd = hsa_device(dev);
-    hsa_amd_memory_access_desc_t d[2] = {{HSA_ACCESS_PERMISSION_RW, hd.agent}, {HSA_ACCESS_PERMISSION_RW, hd.cpu}};
-    HSA_CHECK(hsa_amd_vmem_set_access(va, size, d, hsa_cpu_access().load() && hd.have_cpu ? 2 : 1));
+    hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hd.agent}; // HIP resolves the pointers itself (registered VA)
+    HSA_CHECK(hsa_amd_vmem_set_access(va, size, &d, 1));
   } else {
     const auto acc = make_rw_access(dev);
     HIP_CHECK(hipMemSetAccess(va, size, &acc, 1));
@@ -308,8 +286,8 @@ inline bool vmm_try_set_access(void *va, size_t size, int dev) {
   if (vmm_uses_rocr()) {
     try {
       const HsaDevice &hd = hsa_device(dev);
-      hsa_amd_memory_access_desc_t d[2] = {{HSA_ACCESS_PERMISSION_RW, hd.agent}, {HSA_ACCESS_PERMISSION_RW, hd.cpu}};
-      return hsa_amd_vmem_set_access(va, size, d, hsa_cpu_access().load() && hd.have_cpu ? 2 : 1) == HSA_STATUS_SUCCESS;
+      hsa_amd_memory_access_desc_t d{HSA_ACCESS_PERMISSION_RW, hd.agent};
+      return hsa_amd_vmem_set_access(va, size, &d, 1) == HSA_STATUS_SUCCESS;
     } catch (...) {
       return false;
     }
@@ -365,364 +343,5 @@ inline std::atomic<int64_t> &fail_after_creates() {
   static std::atomic<int64_t> v{-1};
   return v;
 }
-
-struct VmmCounters {
-  std::atomic<int64_t> created{0}, released{0}, reused{0};
-};
-
-// A physical allocation plus the order in which it was created. The order matters on ROCm:
-// hipMemRelease walks a creation-ordered list from its head (3.7 us for the oldest handles, 46 us
-// for the newest, tools/create_diag.cpp) and the hole left at the head makes later hipMemCreate
-// calls O(1) instead of O(live handles). Hence: always release oldest-first.
-struct Phys {
-  phys_handle_t h{};
-  uint64_t seq = 0;
-};
-
-// A bounded set of idle physical allocations of one size on one device. hipMemCreate costs
-// O(live allocations) on ROCm (4 us at 1k live handles, 70-200 us at 20-28k), so recycling is what
-// keeps the map path flat (~10 us/page). Idle handles hold HBM, so the pool is bounded
-// (KVCACHED_PHYS_POOL_MB, default 16384 = 5.5 % of the HBM; trim() empties it) and pressure-aware: when the device's
-// free memory is below the allocator's own headroom (1 - KVCACHED_GPU_UTILIZATION of the total),
-// released handles go straight back to the driver like the reference's GPUPage destructor
-// (csrc/page.cpp:17) and the idle ones are drained (also checked at 10 Hz by the allocator's watcher thread,
-// so an idle engine does not starve a co-located one). Eviction is oldest-created-first.
-class PhysPool {
-public:
-  // `unit`: pages per handle (1, or k when the handles are chunks carved up by a PiecePool): the created/released
-  // counters stay in pages; reuse is then counted per piece by the PiecePool.
-  PhysPool(int dev, size_t granule, bool exportable, VmmCounters *ctr, unsigned unit = 1)
-      : dev_(dev), granule_(granule), exportable_(exportable), ctr_(ctr), unit_(unit) {}
-  ~PhysPool() { drain(0); }
-
-  size_t granule() const { return granule_; }
-  bool exportable() const { return exportable_; }
-  void set_cap_bytes(size_t b) { cap_handles_ = b / granule_; }
-  // Called once before a batch of handles is given back to the driver (their physical memory leaves this
-  // process): the owner uses it to flush a TLB invalidation it had deferred.
-  void set_before_driver_release(std::function<void()> fn) { before_driver_release_ = std::move(fn); }
-
-  // An idle handle if there is one (never creates).
-  bool try_acquire_idle(Phys *out) {
-    std::lock_guard<std::mutex> g(mu_);
-    if (idle_.empty()) return false;
-    auto it = std::prev(idle_.end());
-    *out = Phys{it->second, it->first};
-    idle_.erase(it);
-    low_water_ = std::min(low_water_, idle_.size());
-    if (unit_ == 1) ctr_->reused++;
-    return true;
-  }
-
-  // `recycled` tells the caller whether the memory may hold old data.
-  Phys acquire(bool *recycled) {
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      if (!idle_.empty()) {
-        auto it = std::prev(idle_.end()); // youngest: the old ones stay cheap to give back
-        Phys p{it->second, it->first};
-        idle_.erase(it);
-        low_water_ = std::min(low_water_, idle_.size());
-        if (unit_ == 1) ctr_->reused++;
-        *recycled = true;
-        return p;
-      }
-    }
-    Phys p;
-    if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
-      hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-    p.h = vmm_create(dev_, granule_, exportable_);
-    p.seq = next_seq_.fetch_add(1) + 1;
-    ctr_->created += unit_;
-    *recycled = false;
-    return p;
-  }
-
-  void release(Phys p) { release_batch(&p, 1); }
-
-  // Takes handles back. What exceeds the cap (or everything, under memory pressure) goes to the
-  // driver in creation order, oldest first.
-  // With a housekeeping thread around (defer_eviction), what exceeds the cap is NOT released here, on the
-  // caller's free() path - hipMemRelease of a used handle costs 40-50 us, 200 ms for a 4096-slot free - but
-  // by trim_to_cap() from that thread, a tick later. Under memory pressure the release is immediate either way.
-  void set_defer_eviction(bool on) { defer_eviction_.store(on); }
-  void release_batch(Phys *ps, size_t n) {
-    if (n == 0) return;
-    std::vector<Phys> victims;
-    const bool pressure = under_pressure();
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      for (size_t i = 0; i < n; ++i) idle_.emplace(ps[i].seq, ps[i].h);
-      const size_t keep = pressure ? 0 : (defer_eviction_.load() && cap_handles_ > 0 ? (size_t)-1 : cap_handles_);
-      while (idle_.size() > keep) {
-        auto it = idle_.begin();
-        victims.push_back(Phys{it->second, it->first});
-        idle_.erase(it);
-      }
-    }
-    to_driver(victims);
-  }
-
-  // Housekeeping: bring the idle set back under its cap, at most `max_release` handles per call, oldest first.
-  size_t trim_to_cap(size_t max_release) {
-    std::vector<Phys> victims;
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      while (idle_.size() > cap_handles_ && victims.size() < max_release) {
-        auto it = idle_.begin();
-        victims.push_back(Phys{it->second, it->first});
-        idle_.erase(it);
-      }
-      low_water_ = std::min(low_water_, idle_.size());
-    }
-    to_driver(victims);
-    return victims.size();
-  }
-
-  // Give idle memory back to the driver, keeping at most `keep` (the youngest) handles.
-  void drain(size_t keep) {
-    std::vector<Phys> victims;
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      while (idle_.size() > keep) {
-        auto it = idle_.begin();
-        victims.push_back(Phys{it->second, it->first});
-        idle_.erase(it);
-      }
-    }
-    to_driver(victims);
-  }
-
-  // Idle-time decay (called from the allocator's 10 Hz watcher): the handles nobody needed during a whole
-  // window of `idle_ns` - the low-water mark of the idle set over that window - go back to the driver, at
-  // most `max_release` per call. The pool is a recycling buffer for alloc/free churn, not a place to keep
-  // memory: a co-located engine computes what it may use from hipMemGetInfo and would never see what is
-  // parked here (the reference releases on every unmap, csrc/page.cpp:17).
-  size_t decay(int64_t now_ns, int64_t idle_ns, size_t max_release) {
-    std::vector<Phys> victims;
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      if (window_start_ns_ == 0 || idle_.empty()) {
-        window_start_ns_ = now_ns;
-        low_water_ = idle_.size();
-        return 0;
-      }
-      if (now_ns - window_start_ns_ < idle_ns) return 0;
-      const size_t surplus = std::min(low_water_, idle_.size());
-      const size_t n = std::min(surplus, max_release);
-      for (size_t i = 0; i < n; ++i) {
-        auto it = idle_.begin();
-        victims.push_back(Phys{it->second, it->first});
-        idle_.erase(it);
-      }
-      if (n < surplus) {
-        low_water_ = surplus - n; // keep going at the next tick
-      } else {
-        window_start_ns_ = now_ns;
-        low_water_ = idle_.size();
-      }
-    }
-    to_driver(victims);
-    return victims.size();
-  }
-
-  // hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release batch.
-  bool under_pressure() const {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    static const double util = []() {
-      const char *e = std::getenv("KVCACHED_GPU_UTILIZATION");
-      return e ? std::atof(e) : 0.95;
-    }();
-    return free_b < static_cast<size_t>(total_b * (1.0 - util));
-  }
-  size_t idle_count() {
-    std::lock_guard<std::mutex> g(mu_);
-    return idle_.size();
-  }
-
-  // Release handles that never enter the pool (imports, teardown), oldest first.
-  void to_driver(std::vector<Phys> &v) {
-    if (v.empty()) return;
-    if (before_driver_release_) before_driver_release_();
-    std::sort(v.begin(), v.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; });
-    for (auto &p : v) {
-      if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
-      ctr_->released += unit_;
-    }
-    (void)hipGetLastError();
-  }
-
-private:
-  int dev_;
-  size_t granule_;
-  bool exportable_;
-  VmmCounters *ctr_;
-  unsigned unit_ = 1;
-  size_t cap_handles_ = 0;
-  std::function<void()> before_driver_release_;
-  std::atomic<bool> defer_eviction_{false};
-  std::atomic<uint64_t> next_seq_{0};
-  std::mutex mu_;
-  std::multimap<uint64_t, phys_handle_t> idle_; // creation order -> handle
-  size_t low_water_ = 0;                         // smallest idle_ size since window_start_ns_
-  int64_t window_start_ns_ = 0;
-};
-
-// Page-sized pieces out of a PhysPool of chunks (k pages each; k = 1: a plain pass-through, which is the default and
-// the only mode of the non-drm backends). GEM_VA maps at an offset into a buffer, so any piece can back any slot, and a
-// run of adjacent slots backed by adjacent pieces of one chunk is ONE ioctl (tools/drm_chunk_probe.cpp: 0.18 us per
-// page for runs of 16 against 2.2). Whole idle chunks live in the PhysPool (cap, decay, pressure, eviction all work on
-// chunks); chunks with some pieces out are tracked here and go back to it when their last piece returns. Single pieces
-// are served from partly used chunks first, so that whole chunks stay whole.
-class PiecePool {
-public:
-  PiecePool(PhysPool *chunks, size_t piece_bytes, unsigned k, VmmCounters *ctr)
-      : chunks_(chunks), piece_bytes_(piece_bytes), k_(k), ctr_(ctr), full_(k >= 64 ? ~0ull : ((1ull << k) - 1)) {}
-  PhysPool *chunks() const { return chunks_; }
-  unsigned pieces_per_chunk() const { return k_; }
-
-  // Up to `want` pieces with consecutive indices in one chunk; at least one unless nothing is idle and !may_create
-  // (then 0). *recycled: the memory may hold old data.
-  size_t acquire_run(size_t want, Phys *out, bool *recycled, bool may_create) {
-    if (k_ == 1) {
-      if (may_create) {
-        out[0] = chunks_->acquire(recycled);
-        return 1;
-      }
-      *recycled = true;
-      return chunks_->try_acquire_idle(&out[0]) ? 1 : 0;
-    }
-    want = std::min<size_t>(std::max<size_t>(want, 1), k_);
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      size_t looked = 0;
-      for (auto it = partial_.begin(); it != partial_.end() && looked < 8; ++it, ++looked) { // a partly used chunk with room
-        Chunk &c = tracked_[*it];
-        const int first = find_run(c.free_mask, (unsigned)want);
-        if (first < 0) continue;
-        const phys_handle_t h = *it;
-        const unsigned old = take(h, c, (unsigned)first, (unsigned)want, out);
-        *recycled = old > 0;
-        ctr_->reused += old;
-        return want;
-      }
-    }
-    // No partly used chunk has `want` neighbours free. A whole idle chunk costs nothing new; failing that, whatever
-    // free pieces exist are used up - a shorter run now, the caller comes back for the rest - BEFORE a new chunk is
-    // made: physical memory allocated never exceeds what is mapped by more than one chunk's worth of pieces
-    // (opening a chunk per run tripled the footprint of the Poisson workload).
-    Phys c;
-    bool rec = true;
-    if (!chunks_->try_acquire_idle(&c)) {
-      {
-        std::lock_guard<std::mutex> g(mu_);
-        if (!partial_.empty()) {
-          const phys_handle_t h = *partial_.begin();
-          Chunk &pc = tracked_[h];
-          unsigned n = (unsigned)want;
-          int first = -1;
-          while (n >= 1 && (first = find_run(pc.free_mask, n)) < 0) --n; // the longest run this chunk still has, up to `want`
-          const unsigned old = take(h, pc, (unsigned)first, n, out);
-          *recycled = old > 0;
-          ctr_->reused += old;
-          return n;
-        }
-      }
-      if (!may_create) return 0;
-      c = chunks_->acquire(&rec); // may throw: nothing of ours has changed yet
-    }
-    std::lock_guard<std::mutex> g(mu_);
-    Chunk &t = tracked_[c.h];
-    t.seq = c.seq;
-    t.free_mask = full_;
-    t.used_mask = rec ? full_ : 0; // a chunk from the idle pool has been used all over, a new one nowhere
-    free_pieces_ += k_;
-    const unsigned old = take(c.h, t, 0, (unsigned)want, out);
-    *recycled = old > 0;
-    ctr_->reused += old;
-    return want;
-  }
-
-  void release(Phys p) { release_batch(&p, 1); }
-  void release_batch(Phys *ps, size_t n) {
-    if (n == 0) return;
-    if (k_ == 1) {
-      chunks_->release_batch(ps, n);
-      return;
-    }
-    std::vector<Phys> whole;
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      for (size_t i = 0; i < n; ++i) {
-        const phys_handle_t h = chunk_of(ps[i].h);
-        auto it = tracked_.find(h);
-        if (it == tracked_.end()) {
-          KVC_LOG(LOG_ERROR, "a piece of an unknown chunk was released");
-          continue;
-        }
-        it->second.free_mask |= 1ull << piece_of(ps[i].h);
-        ++free_pieces_;
-        if (it->second.free_mask == full_) {
-          free_pieces_ -= k_; // the chunk goes back whole: counted by the chunk pool from here on
-          whole.push_back(Phys{h, it->second.seq});
-          partial_.erase(h);
-          tracked_.erase(it);
-        } else {
-          partial_.insert(h);
-        }
-      }
-    }
-    if (!whole.empty()) chunks_->release_batch(whole.data(), whole.size());
-  }
-  // bytes of free pieces inside partly used chunks: ours to reuse, invisible to hipMemGetInfo
-  size_t free_piece_bytes() {
-    if (k_ == 1) return 0;
-    std::lock_guard<std::mutex> g(mu_);
-    return free_pieces_ * piece_bytes_;
-  }
-
-private:
-  struct Chunk {
-    uint64_t seq = 0;
-    uint64_t free_mask = 0;
-    uint64_t used_mask = 0; // pieces that have been handed out before (their memory may hold old data)
-  };
-  // lowest start of `want` consecutive free pieces, or -1
-  int find_run(uint64_t mask, unsigned want) const {
-    uint64_t m = mask;
-    for (unsigned s = 1; s < want && m; ++s) m &= mask >> s;
-    return m ? __builtin_ctzll(m) : -1;
-  }
-  // returns how many of the pieces taken had been in use before
-  unsigned take(phys_handle_t h, Chunk &c, unsigned first, unsigned n, Phys *out) {
-    unsigned old = 0;
-    for (unsigned i = 0; i < n; ++i) {
-      const uint64_t bit = 1ull << (first + i);
-      c.free_mask &= ~bit;
-      --free_pieces_;
-      old += (c.used_mask & bit) != 0;
-      c.used_mask |= bit;
-      out[i] = Phys{piece_id(h, first + i), c.seq};
-    }
-    if (c.free_mask)
-      partial_.insert(h);
-    else
-      partial_.erase(h);
-    return old;
-  }
-  PhysPool *chunks_;
-  size_t piece_bytes_;
-  unsigned k_;
-  VmmCounters *ctr_;
-  uint64_t full_;
-  std::mutex mu_;
-  size_t free_pieces_ = 0;                            // free pieces inside tracked chunks
-  std::unordered_map<phys_handle_t, Chunk> tracked_; // chunks with at least one piece handed out
-  std::set<phys_handle_t> partial_;                   // ... of which some pieces are free
-};
 
 } // namespace kvc

@@ -91,6 +91,21 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- peek_poke (init self test)
+// One lane writes `value` to *p (if do_write) and copies *p to *out, with system-scope loads/stores that bypass nothing
+// they should not: what the TLB self test of KvAllocator::init looks at memory with (through the GPU's own address
+// translation, which is the thing under test - a host copy would go another way).
+__global__ void peek_poke_kernel(unsigned *p, unsigned *out, unsigned value, int do_write) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (do_write) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *out = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+hipError_t launch_peek_poke(void *p, unsigned *out_dev, unsigned value, bool do_write, hipStream_t stream) {
+  peek_poke_kernel<<<dim3(1), dim3(64), 0, stream>>>(static_cast<unsigned *>(p), out_dev, value, do_write ? 1 : 0);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- compact_blocks
 struct CompactArgs {
   void *base[kMaxRegionsPerLaunch];

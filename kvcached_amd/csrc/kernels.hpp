@@ -30,6 +30,9 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant = 0);
 
+// One lane: optionally store `value` to *p, then copy *p to *out_dev (the TLB self test's view of memory).
+hipError_t launch_peek_poke(void *p, unsigned *out_dev, unsigned value, bool do_write, hipStream_t stream);
+
 // ---- index_kernels.hip. Block ids come either from the host (`ids_host`, <= kMaxIdsPerLaunch, carried in the
 // kernarg) or from device memory (`ids_dev` != nullptr, any count). All asynchronous on `stream`.
 // out[i*tpb + j] = ids[i]*tpb + j

@@ -86,11 +86,14 @@ GpuContext::GpuContext(int dev) : dev_(dev) {
     throw InvalidError("Invalid page size: " + std::to_string(g_page_size) + " must be a multiple of HIP granularity " +
                        std::to_string(gran));
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (env_bool("KVCACHED_KFD_TLB_FLUSH", true)) {
+    std::string why;
+    if (!kfd_flush_.open(dev_, &why))
+      KVC_LOG(LOG_WARNING, "direct KFD TLB flush unavailable (%s): invalidating through hipMalloc + hipFree", why.c_str());
+  }
 }
 
 GpuContext::~GpuContext() {
-  piece_pools_[0].clear();
-  piece_pools_[1].clear();
   {
     std::lock_guard<std::mutex> g(fl_mu_);
     fl_stop_ = true;
@@ -106,8 +109,9 @@ GpuContext::~GpuContext() {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
-  pools_[0].clear();
-  pools_[1].clear();
+  extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
+  extent_pools_[1].clear();
+  kfd_flush_.close();
   if (uniq_bitmap_) (void)hipFree(uniq_bitmap_);
   if (uniq_header_) (void)hipFree(uniq_header_);
   if (uniq_result_) (void)hipHostFree(uniq_result_);
@@ -116,91 +120,86 @@ GpuContext::~GpuContext() {
 
 void GpuContext::bind() const { HIP_CHECK(hipSetDevice(dev_)); }
 
-PhysPool *GpuContext::pool(size_t granule, bool exportable) {
+namespace {
+// hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release batch.
+bool device_under_pressure() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  static const double util = []() {
+    const char *e = std::getenv("KVCACHED_GPU_UTILIZATION");
+    return e ? std::atof(e) : 0.95;
+  }();
+  return free_b < static_cast<size_t>(total_b * (1.0 - util));
+}
+} // namespace
+
+ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
+  // Run-sized extents need a map offset (GEM_VA has one; HIP rejects it, ROCr ignores it), ranged unmaps and buffers of
+  // our own making: the drm backend with pages straight from KFD. Everything else works with single pages.
+  unsigned k = 1;
+  if (!exportable && vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && DrmVm::instance().can_clear())
+    k = (unsigned)std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, options().phys_chunk_pages.load()));
+  k = (unsigned)std::min<size_t>(k, std::max<size_t>(1, (256u << 20) / page_bytes)); // no buffer above 256 MiB (8 MiB pages, compound pages)
   std::lock_guard<std::mutex> g(mu_);
-  auto &m = pools_[exportable ? 1 : 0];
-  auto it = m.find(granule);
-  if (it == m.end()) {
-    it = m.emplace(granule, std::make_unique<PhysPool>(dev_, granule, exportable, &stats().vmm)).first;
-    it->second->set_before_driver_release([this]() { flush_deferred_shootdown(); });
+  auto &m = extent_pools_[exportable ? 1 : 0];
+  auto it = m.find(page_bytes);
+  if (it == m.end() || it->second->max_extent_pages() != k) {
+    // (re)made at the first use after an init that changed the extent size: no region exists then, every piece is home
+    ExtentDriver d;
+    const int dev = dev_;
+    d.create = [dev, page_bytes, exportable](size_t pages) -> phys_handle_t {
+      if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
+        hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
+      return vmm_create(dev, pages * page_bytes, exportable);
+    };
+    d.release = [](phys_handle_t h) {
+      const bool ok = vmm_try_release(h);
+      if (!ok) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
+      (void)hipGetLastError();
+      return ok;
+    };
+    d.before_release = [this]() { flush_deferred_shootdown(); }; // memory leaves the process: no translation of it may survive
+    d.under_pressure = device_under_pressure;
+    m[page_bytes] = std::make_unique<ExtentPool>(page_bytes, k, std::move(d), &stats().vmm);
+    it = m.find(page_bytes);
     it->second->set_defer_eviction(housekeepers_.load() > 0);
   }
   it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  it->second->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
   return it->second.get();
 }
 
-PiecePool *GpuContext::pieces(size_t page_bytes, bool exportable) {
-  unsigned k = 1;
-  if (!exportable && vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && DrmVm::instance().can_clear())
-    k = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, options().phys_chunk_pages.load()));
-  PhysPool *chunks;
-  if (k == 1) {
-    chunks = pool(page_bytes, exportable);
-  } else {
-    std::lock_guard<std::mutex> g(mu_);
-    auto &m = pools_[0];
-    const size_t key = page_bytes * k + 1; // odd: cannot collide with the pool of a real granule
-    auto it = m.find(key);
-    if (it == m.end()) {
-      it = m.emplace(key, std::make_unique<PhysPool>(dev_, page_bytes * k, false, &stats().vmm, k)).first;
-      it->second->set_before_driver_release([this]() { flush_deferred_shootdown(); });
-      it->second->set_defer_eviction(housekeepers_.load() > 0);
-    }
-    it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
-    chunks = it->second.get();
-  }
+std::vector<ExtentPool *> GpuContext::all_pools() {
   std::lock_guard<std::mutex> g(mu_);
-  auto &pm = piece_pools_[exportable ? 1 : 0];
-  auto it = pm.find(page_bytes);
-  if (it == pm.end() || it->second->pieces_per_chunk() != k || it->second->chunks() != chunks) {
-    // (re)made at the first use after an init that changed the chunking: no region exists then, every piece is home
-    pm[page_bytes] = std::make_unique<PiecePool>(chunks, page_bytes, k, &stats().vmm);
-    it = pm.find(page_bytes);
-  }
-  return it->second.get();
+  std::vector<ExtentPool *> ps;
+  for (auto &m : extent_pools_)
+    for (auto &kv : m) ps.push_back(kv.second.get());
+  return ps;
 }
 
 void GpuContext::drain_pools() {
-  std::vector<PhysPool *> ps;
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    for (auto &m : pools_)
-      for (auto &kv : m) ps.push_back(kv.second.get());
-  }
-  for (auto *p : ps) p->drain(0);
+  for (auto *p : all_pools()) p->drain(0);
 }
 
 size_t GpuContext::idle_pool_bytes() {
-  std::lock_guard<std::mutex> g(mu_);
   size_t b = 0;
-  for (auto &m : pools_)
-    for (auto &kv : m) b += kv.second->idle_count() * kv.second->granule();
-  for (auto &m : piece_pools_)
-    for (auto &kv : m) b += kv.second->free_piece_bytes();
+  for (auto *p : all_pools()) b += p->idle_bytes();
   return b;
 }
 
 void GpuContext::add_housekeeper(int delta) {
   const bool on = housekeepers_.fetch_add(delta) + delta > 0;
-  std::vector<PhysPool *> ps;
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    for (auto &m : pools_)
-      for (auto &kv : m) ps.push_back(kv.second.get());
-  }
-  for (auto *p : ps) {
+  for (auto *p : all_pools()) {
     p->set_defer_eviction(on);
     if (!on) p->trim_to_cap((size_t)-1); // nobody will do it later
   }
 }
 
 void GpuContext::housekeeping() {
-  std::vector<PhysPool *> ps;
-  {
-    std::lock_guard<std::mutex> g(mu_);
-    for (auto &m : pools_)
-      for (auto &kv : m) ps.push_back(kv.second.get());
-  }
+  auto ps = all_pools();
   if (ps.empty()) return;
   (void)hipSetDevice(dev_);
   tl_background_thread = true; // the allocator's watcher thread
@@ -209,18 +208,25 @@ void GpuContext::housekeeping() {
   } catch (const std::exception &e) {
     KVC_LOG(LOG_ERROR, "housekeeping: TLB invalidation failed: %s", e.what());
   }
-  if (ps[0]->under_pressure()) {
+  if (device_under_pressure()) {
     for (auto *p : ps) p->drain(0);
     return;
   }
-  // Releasing memory the GPU has touched costs 50-60 us per handle (the KFD free ioctl) and driver calls of one
-  // process do not overlap: 256 handles per 100 ms tick keeps this thread's share of the driver under ~15 % while
+  // Releasing memory the GPU has touched costs 50-70 us per 2 MiB (the kernel wipes it) and driver calls of one
+  // process do not overlap: 256 pages per 100 ms tick keeps this thread's share of the driver under ~15 % while
   // still returning 5 GiB/s.
   constexpr size_t kPerTick = 256;
   for (auto *p : ps) p->trim_to_cap(kPerTick); // what release_batch left above the cap (deferred eviction)
   const int64_t idle_ms = options().pool_idle_ms.load();
-  if (idle_ms > 0)
-    for (auto *p : ps) p->decay(now_ns(), idle_ms * 1000000ll, kPerTick);
+  const size_t reserve_b = (size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load());
+  for (auto *p : ps) {
+    // the reserve belongs to the pool the engine's own pages come from (not to the exportable twin)
+    const size_t floor_pages = (p == ps[0] || ps.size() == 1) ? reserve_b / p->page_bytes() : 0;
+    if (idle_ms > 0) p->decay(now_ns(), idle_ms * 1000000ll, kPerTick, floor_pages);
+    // Growth into VRAM the kernel has not cleared yet costs ~80 us per 2 MiB inside the allocation (one SDMA ring,
+    // ~30 GB/s: profiles/r02_create_cost.jsonl); this thread pays that ahead of time, off every caller's path.
+    if (floor_pages) p->refill_reserve(floor_pages, kPerTick);
+  }
 }
 
 void GpuContext::begin_timed(hipStream_t s, int kind) {
@@ -438,21 +444,29 @@ void GpuContext::tlb_shootdown() {
 void GpuContext::do_shootdown() {
   tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
   if (!options().tlb_shootdown.load()) return;
+  static const bool broken_for_test = env_bool("KVCACHED_TEST_BREAK_TLB_FLUSH", false); // hook: the init self test must notice
   const int64_t t0 = now_ns();
-  void *p = nullptr;
-  // 2 MiB is the smallest size ROCr does not serve from its sub-allocator, i.e. the cheapest
-  // allocation that reaches the kernel driver (measured: 4 KiB has no effect, 2 MiB ~0.22 ms).
-  HIP_CHECK(hipMalloc(&p, 2u << 20));
-  HIP_CHECK(hipFree(p));
-  if (now_ns() - t0 < 20000) {
-    // A real trip to the kernel driver takes >150 us on MI355X (profiles/r01_remap_diag_tlb.log). Faster
-    // than 20 us means the runtime served the block from a cache and nothing was invalidated (other
-    // candidates - host-page registration, small blocks - are cached that way, profiles/r02_tlb_triggers.log):
-    // a block too large for any cache is the fallback.
-    static std::atomic<bool> warned{false};
-    if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: 2 MiB allocation did not reach the driver; using 64 MiB blocks");
-    HIP_CHECK(hipMalloc(&p, 64u << 20));
+  if (broken_for_test) {
+    // nothing: what a runtime that stopped flushing would look like
+  } else if (kfd_flush_.ready()) {
+    // The ioctl pair that ends in KFD's heavyweight flush, on our own buffer: nothing between us and the kernel can
+    // answer it from a cache.
+    if (!kfd_flush_.flush()) throw GpuError(std::string("KFD TLB flush failed: ") + strerror(errno));
+  } else {
+    // Fallback where /dev/kfd cannot be driven directly: an allocation that reaches KFD. 2 MiB is the smallest size
+    // ROCr does not serve from its sub-allocator (measured: 4 KiB has no effect, 2 MiB ~0.22 ms). A real trip to the
+    // kernel takes >150 us on MI355X; one that returns in <20 us was served from a cache and invalidated nothing, so a
+    // block too large for any cache is used instead. (Only this fallback watches the clock; init's self test has
+    // checked that it invalidates at all.)
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, 2u << 20));
     HIP_CHECK(hipFree(p));
+    if (now_ns() - t0 < 20000) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: 2 MiB allocation did not reach the driver; using 64 MiB blocks");
+      HIP_CHECK(hipMalloc(&p, 64u << 20));
+      HIP_CHECK(hipFree(p));
+    }
   }
   stats().tlb_shootdowns++;
   if (tl_background_thread) background_shootdowns()++;
@@ -672,18 +686,110 @@ bool drm_self_test(int dev) {
   (void)hipGetLastError();
   return ok;
 }
+
+// Does the TLB invalidation in effect (GpuContext::tlb_shootdown: the KFD ioctl pair, or its hipMalloc fallback)
+// really invalidate, with the backend in effect? Two pages swapped under one VA, looked at through the GPU's own
+// address translation (a one-lane kernel): after A has been used through the VA and B mapped in its place, a write
+// through the VA must land in B - if it lands in A (found when A is mapped back), the translation survived the
+// invalidation, and pages recycled between requests or engines would leak into each other. No fallback makes that
+// acceptable: init fails (tests/test_gpu_vmm.py::test_init_refuses_to_start_when_tlb_invalidation_is_ineffective
+// breaks the flush with a hook and expects exactly that).
+void tlb_self_test(GpuContext *ctx) {
+  const size_t ps = kBasePage;
+  const int dev = ctx->dev();
+  void *va = nullptr;
+  unsigned *out = nullptr;
+  phys_handle_t a = 0, b = 0, mapped = 0;
+  std::string failure;
+  auto look = [&](unsigned value, bool write) -> unsigned {
+    unsigned host = 0;
+    HIP_CHECK(launch_peek_poke(va, out, value, write, ctx->stream()));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream()));
+    HIP_CHECK(hipMemcpy(&host, out, sizeof host, hipMemcpyDeviceToHost));
+    return host;
+  };
+  auto put = [&](phys_handle_t h) {
+    if (vmm_map(va, ps, h)) vmm_set_access(va, ps, dev);
+    mapped = h;
+  };
+  auto take = [&]() {
+    vmm_unmap(va, ps, mapped);
+    mapped = 0;
+  };
+  try {
+    va = vmm_reserve(ps, ps, nullptr);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&out), 64));
+    a = vmm_create(dev, ps, false);
+    b = vmm_create(dev, ps, false);
+    put(a);
+    if (look(0x5a5a5a5au, true) != 0x5a5a5a5au) throw GpuError("a freshly mapped page does not read back what was written");
+    take();
+    put(b);               // the VA's translation to A may still be cached ...
+    ctx->tlb_shootdown(); // ... until now (the path every unmap batch takes)
+    if (look(0xc3c3c3c3u, true) != 0xc3c3c3c3u) throw GpuError("the second page does not read back what was written");
+    take();
+    put(a);
+    ctx->tlb_shootdown();
+    const unsigned seen = look(0, false);
+    if (seen != 0x5a5a5a5au) {
+      char buf[200];
+      snprintf(buf, sizeof buf, "a write through a re-mapped VA landed in the page that had been unmapped (0x%08x where 0x5a5a5a5a "
+               "was expected): the GPU kept a stale translation across the invalidation", seen);
+      failure = buf;
+    }
+  } catch (const std::exception &e) {
+    failure = e.what();
+  }
+  (void)hipGetLastError();
+  if (mapped) (void)vmm_try_unmap(va, ps, mapped);
+  try {
+    ctx->tlb_shootdown(); // the scratch pages were touched through this VA: nothing of it may survive them
+  } catch (...) {
+  }
+  if (a) (void)vmm_try_release(a);
+  if (b) (void)vmm_try_release(b);
+  if (out) (void)hipFree(out);
+  if (va) (void)vmm_try_address_free(va, ps);
+  (void)hipGetLastError();
+  if (!failure.empty())
+    throw GpuError("kvcached_amd: TLB invalidation is ineffective on this system (" + failure +
+                   "). Pages could leak between requests and co-located engines: refusing to start.");
+}
 } // namespace
 
 // ------------------------------------------------------------------ registry
 void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contiguous_layout) {
   std::unordered_map<int64_t, std::unique_ptr<KvAllocator>> old; // destroyed after g_mu is released
   std::unique_lock<std::mutex> g(g_mu);
+  const DeviceSpec want_dev = parse_device(dev_str);
   if (!g_allocators.empty()) {
+    // One device per process (as in the reference: one FTensorAllocator multiton, allocator.cpp:18-22). Re-initialising
+    // for the SAME device re-creates the allocators like the reference does (allocator.cpp:75-78); asking for another
+    // device while KV tensors of the first one exist would pull the driver state (DrmVm, pooled pages) from under them.
+    const bool other_device = want_dev.is_gpu != g_device.is_gpu ||
+                              (want_dev.is_gpu && want_dev.index >= 0 && want_dev.index != g_device.index);
+    if (other_device) {
+      bool live = false;
+      for (auto &kv : g_allocators) live = live || kv.second->kv_tensors_created();
+      if (live)
+        throw InvalidError("init_kvcached(\"" + dev_str + "\") while KV tensors of " +
+                           (g_device.is_gpu ? "cuda:" + std::to_string(g_device.index) : std::string("cpu")) +
+                           " exist: one device per process - call shutdown_kvcached() first");
+    }
     KVC_LOG(LOG_ERROR, "KvAllocator has been initialized. Re-initializing...");
     old.swap(g_allocators);
+    g_initialized = false; // until this init has succeeded
     g.unlock();
     old.clear();
     g.lock();
+    if (other_device) { // nothing of the old device may linger in pools that DrmVm::open() is about to invalidate
+      std::unordered_map<int, std::unique_ptr<GpuContext>> ctxs;
+      ctxs.swap(g_contexts);
+      g.unlock();
+      for (auto &kv : ctxs) kv.second->drain_pools();
+      ctxs.clear();
+      g.lock();
+    }
   }
   if (page_size > 0) {
     if (page_size % kBasePage != 0) // reference aborts here (allocator.cpp:84-90); we report it
@@ -705,7 +811,9 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   options().hip_reg_group_mb = std::max<int64_t>(0, env_i64("KVCACHED_HIP_REG_GROUP_MB", 64));
   options().clear_run_slots = std::max<int64_t>(0, env_i64("KVCACHED_DRM_CLEAR_RUN", 16));
-  options().phys_chunk_pages = std::min<int64_t>(64, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 1)));
+  options().phys_chunk_pages = std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 32)));
+  options().extent_waste_pct = std::min<int64_t>(100, std::max<int64_t>(0, env_i64("KVCACHED_EXTENT_WASTE_PCT", 5)));
+  options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 1024)) << 20;
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -713,23 +821,23 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   {
     const char *be = std::getenv("KVCACHED_VMM_BACKEND");
     const std::string b = be ? be : "drm";
-    if (b != "hip" && b != "hsa" && b != "hybrid" && b != "drm")
-      throw InvalidError("KVCACHED_VMM_BACKEND must be 'hip', 'hybrid', 'drm' or 'hsa'");
-    const int want = b == "hsa" ? kVmmHsa : (b == "hybrid" ? kVmmHybrid : (b == "drm" ? kVmmDrm : kVmmHip));
-    if (want != vmm_backend().load())
-      for (auto &kv : g_contexts) kv.second->drain_pools(); // pooled handles belong to the backend that made them
+    if (b != "hip" && b != "hybrid" && b != "drm")
+      throw InvalidError("KVCACHED_VMM_BACKEND must be 'drm', 'hybrid' or 'hip'");
+    const int want = b == "hybrid" ? kVmmHybrid : (b == "drm" ? kVmmDrm : kVmmHip);
+    // Pooled handles belong to the backend that made them; init's self tests may yet change the backend, and the
+    // extent size may differ too: start every init with empty pools.
+    for (auto &kv : g_contexts) kv.second->drain_pools();
     vmm_backend() = want;
-    hsa_cpu_access() = (want == kVmmHsa && env_bool("KVCACHED_HSA_CPU_ACCESS", true)) ? 1 : 0; // hybrid: HIP resolves the pointers itself
   }
   options().access_run_slots = std::max<int64_t>(1, env_i64("KVCACHED_ACCESS_RUN_SLOTS", 1));
   options().zero_alias_fanout = std::max<int64_t>(1, env_i64("KVCACHED_ZERO_ALIAS_FANOUT", 256));
   options().fill_chunk_slots = std::max<int64_t>(1, env_i64("KVCACHED_FILL_CHUNK_SLOTS", 1024));
-  g_device = parse_device(dev_str);
+  g_device = want_dev;
   g_contiguous = contiguous_layout;
   if (g_device.is_gpu) {
     HIP_CHECK(hipInit(0));
     g_device.index = resolve_dev_index(g_device);
-    context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
+    GpuContext *ctx = context_for(g_device.index); // validates VMM support + granularity (reference: allocator.cpp:324-343)
     if (vmm_hip_registered() && !hybrid_self_test(g_device.index)) {
       KVC_LOG(LOG_WARNING, "hybrid VMM backend failed its self test on this HIP runtime: using the plain HIP backend "
                            "(KVCACHED_VMM_BACKEND=hip), map/unmap will be ~2x slower");
@@ -740,6 +848,9 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
       DrmVm::instance().close();
       vmm_backend() = kVmmHybrid;
     }
+    // Whatever backend is left standing: pages are only private if unmapping them really invalidates the GPU's TLBs.
+    // No fallback for that - init fails.
+    if (options().tlb_shootdown.load()) tlb_self_test(ctx);
   }
   g_allocators[0] = std::make_unique<KvAllocator>(g_device, contiguous_layout,
                                                   g_device.is_gpu ? context_for(g_device.index) : nullptr);
@@ -1086,15 +1197,14 @@ void KvAllocator::destroy_region(KvRegion &r) {
     whole = vmm_try_unmap(r.base, r.size);
     if (!whole) KVC_LOG(LOG_ERROR, "unmapping the whole region %s in one call failed", r.name.c_str());
   }
-  std::vector<Phys> dead, pieces; // pieces: pages that are parts of chunks (KVCACHED_PHYS_CHUNK_PAGES) go home through their pool
-  PiecePool *pp = ctx ? ctx->pieces(r.page_size, exportable_) : nullptr;
-  const bool chunked = pp && pp->pieces_per_chunk() > 1;
+  std::vector<Phys> dead, pieces; // dead: a peer's pages (imports); pieces: our own, which go home through their pool
+  ExtentPool *pp = ctx ? ctx->extents(r.page_size, exportable_) : nullptr;
   for (size_t i = 0; i < r.num_slots(); ++i) {
     if (!r.mapped[i]) continue;
     if (!whole) {
       if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
-    (chunked && r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
+    (r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
   }
   std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
@@ -1113,7 +1223,10 @@ void KvAllocator::destroy_region(KvRegion &r) {
     if (!vmm_try_release(p.h)) KVC_LOG(LOG_ERROR, "releasing a physical handle during cleanup failed");
     stats().vmm.released++;
   }
-  if (!pieces.empty()) pp->release_batch(pieces.data(), pieces.size()); // whole chunks end up in the chunk pool (drained at shutdown)
+  if (!pieces.empty()) {
+    pp->release_batch(pieces.data(), pieces.size());
+    pp->drain(0); // a region that goes away gives its memory back (the reference releases in ~FTensor, ftensor.cpp:78-98)
+  }
   for (auto z : r.zero) (void)vmm_try_release(z);
   r.zero.clear();
   if (!vmm_try_address_free(r.base, r.size)) KVC_LOG(LOG_ERROR, "freeing the VA range of %s failed", r.name.c_str());
@@ -1287,7 +1400,7 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
     vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
-    if (piece_of(r.handle[s.index]) != 0 || ctx_->pieces(ps, exportable_)->pieces_per_chunk() > 1) // (see unmap_collect)
+    if (pages_of(r.handle[s.index]) > 1) // one page out of a larger mapping: see unmap_collect
       if (void *bo = vmm_direct_bo(r.handle[s.index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
@@ -1326,7 +1439,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   GpuContext *ctx = ctx_;
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
-  PiecePool *pool = ctx->pieces(ps, exportable_);
+  ExtentPool *pool = ctx->extents(ps, exportable_);
   const bool fill = options().zero_fill.load() && !imported;
   const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
 
@@ -1387,9 +1500,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   };
 
   std::vector<Slot> kept; // async unmap: released but not yet unmapped -> simply kept, only zero-filled again
-  // Chunked physical memory (KVCACHED_PHYS_CHUNK_PAGES > 1, drm backend): the unbacked slots of the batch are collected
-  // first and then backed run by run - adjacent slots get adjacent pieces of one chunk and ONE map ioctl.
-  const bool chunked = pool->pieces_per_chunk() > 1 && !imported;
+  // Run-sized extents (KVCACHED_PHYS_CHUNK_PAGES > 1, drm backend): the unbacked slots of the batch are collected
+  // first and then backed run by run - adjacent slots get adjacent pages of one buffer and ONE map ioctl.
+  const bool chunked = pool->multi_page() && !imported;
   std::vector<Slot> fresh;
   try {
     for (auto &s : slots) {
@@ -1469,7 +1582,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       std::sort(fresh.begin(), fresh.end(), [](const Slot &a, const Slot &b) {
         return a.region != b.region ? a.region < b.region : a.index < b.index;
       });
-      std::vector<Phys> got(pool->pieces_per_chunk());
+      std::vector<Phys> got(kMaxExtentPages);
       for (size_t i = 0; i < fresh.size();) {
         size_t j = i + 1;
         while (j < fresh.size() && fresh[j].region == fresh[i].region && fresh[j].index == fresh[j - 1].index + 1) ++j;
@@ -1521,7 +1634,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
       (void)vmm_try_unmap(va, ps, r.handle[it->index]);
-      if (chunked)
+      if (pages_of(r.handle[it->index]) > 1)
         if (void *bo = vmm_direct_bo(r.handle[it->index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
       if (r.mapped[it->index] == 1)
         pool->release(Phys{r.handle[it->index], r.seq[it->index]});
@@ -1573,16 +1686,17 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     run_len = 0;
   };
   u.own.reserve(slots.size());
-  // chunked physical memory: pages may have been mapped together with their neighbours in one ioctl; taking some of them
+  // Pages of a multi-page extent may have been mapped together with their neighbours in one ioctl; taking some of them
   // out splits that mapping, and what is left of it must be rewritten (DrmVm::refresh_mappings_of) before the TLBs are
-  // invalidated
-  const bool chunked_unmap = ctx->pieces(ps, exportable_)->pieces_per_chunk() > 1;
+  // invalidated. An extent that loses ALL its mapped pages in this batch leaves nothing behind to rewrite.
+  ExtentPool *xpool = ctx->extents(ps, exportable_);
   std::vector<phys_handle_t> touched;
   // drm backend, lazy regions: slots of this batch that are neighbours in VA go in runs - one CLEAR ioctl per run of up
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
   std::vector<uint8_t> cleared(slots.size(), 0);
-  const size_t max_clear = (size_t)options().clear_run_slots.load();
+  size_t max_clear = (size_t)options().clear_run_slots.load();
+  if (max_clear >= 2 && xpool->multi_page()) max_clear = std::max<size_t>(max_clear, xpool->max_extent_pages()); // a whole extent in one go
   if (max_clear >= 2 && slots.size() >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
     std::vector<uint32_t> order;
     order.reserve(slots.size());
@@ -1627,13 +1741,14 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       vmm_unmap(va, ps, r.handle[s.index]);
       stats().t_unmap += now_ns() - t0;
     }
-    if (r.mapped[s.index] == 1)
+    const bool own = r.mapped[s.index] == 1;
+    if (own)
       u.own.push_back(Phys{r.handle[s.index], r.seq[s.index]});
     else
       u.imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
     ++u.n;
-    if (chunked_unmap) touched.push_back(chunk_of(r.handle[s.index]));
+    if (own && pages_of(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();
@@ -1649,10 +1764,15 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   flush_run();
   if (!touched.empty() && !env_bool("KVCACHED_TEST_SKIP_REMAINDER_REFRESH", false)) { // hook: prove the test has teeth
     std::sort(touched.begin(), touched.end());
-    touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-    for (auto c : touched)
-      if (void *bo = DrmVm::instance().find(c))
-        if (!DrmVm::instance().refresh_mappings_of(bo, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of a chunk failed");
+    for (size_t i = 0; i < touched.size();) {
+      size_t j = i;
+      while (j < touched.size() && touched[j] == touched[i]) ++j;
+      // pieces still handed out beyond the ones this batch takes back = pages of the extent that stay mapped
+      if (xpool->pieces_out(touched[i]) > j - i)
+        if (void *bo = DrmVm::instance().find(touched[i]))
+          if (!DrmVm::instance().refresh_mappings_of(bo, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of an extent failed");
+      i = j;
+    }
     tlb_stale().store(true);
   }
 }
@@ -1662,13 +1782,13 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
 void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   if (!u.n) return;
   GpuContext *ctx = ctx_;
-  PiecePool *pool = ctx->pieces(u.page_size, exportable_);
+  ExtentPool *pool = ctx->extents(u.page_size, exportable_);
   // Stale TLB entries still translate the unmapped VAs to the old physical pages. Who can be hurt by them?
   //   * a reader of the VA itself: only in compat mode is that legal (unbacked VA reads as zeros), so there the
   //     invalidation happens now;
   //   * the next owner of the physical page: if it stays in OUR pool, its next use is a map_slots() batch, which
   //     invalidates before anything touches the page - the invalidation CAN wait for that (or for the moment the
-  //     pool gives handles back to the driver: PhysPool::set_before_driver_release). Optional and off by default
+  //     pool gives handles back to the driver: ExtentDriver::before_release). Optional and off by default
   //     (KVC_OPT_DEFER_UNMAP_SHOOTDOWN): measured, the cost is conserved, not saved - the invalidation mostly waits
   //     for the page-table updates the unmaps queued, so it only moves from free() into the next alloc()
   //     (per page: unmap 354 -> 21 us, next map 205 -> 379 us; batches unchanged).

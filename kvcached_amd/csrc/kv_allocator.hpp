@@ -34,7 +34,9 @@ struct Options {
   std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
   std::atomic<int64_t> hip_reg_group_mb{64};     // hybrid/drm: VA introduced to HIP per hipMemMap (0 = slot by slot)
   std::atomic<int64_t> clear_run_slots{16};      // drm backend: unmap runs of adjacent slots with one CLEAR ioctl (0 = off)
-  std::atomic<int64_t> phys_chunk_pages{1};      // drm backend: physical memory in chunks of this many pages (1 = off)
+  std::atomic<int64_t> phys_chunk_pages{32};     // drm backend: a run of adjacent slots is backed by ONE buffer of up to this many pages (1 = off)
+  std::atomic<int64_t> extent_waste_pct{5};      // ... and new extents shrink while free pieces of partly used ones exceed this share of the pages in use
+  std::atomic<int64_t> phys_reserve_bytes{0};    // idle physical memory the housekeeping thread keeps ready (pre-created, never below it)
   std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
@@ -71,14 +73,13 @@ public:
   int dev() const { return dev_; }
   void bind() const; // hipSetDevice for the calling thread (HIP's current device is per thread)
   hipStream_t stream() const { return stream_; }
-  PhysPool *pool(size_t granule, bool exportable);
-  // What map/unmap take pages from: page-sized pieces of chunks of KVCACHED_PHYS_CHUNK_PAGES pages (drm backend with
-  // pages straight from KFD, non-exportable pools), or - the default, k = 1 - a pass-through to pool().
-  PiecePool *pieces(size_t page_bytes, bool exportable);
+  // What map/unmap take pages from (extent_pool.hpp): run-sized extents of up to KVCACHED_PHYS_CHUNK_PAGES pages with
+  // the drm backend and pages straight from KFD (non-exportable pools), single pages everywhere else.
+  ExtentPool *extents(size_t page_bytes, bool exportable);
   void drain_pools();
   size_t idle_pool_bytes(); // physical memory parked in the handle pools: ours to reuse, invisible to hipMemGetInfo
   // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
-  // let handles that sat idle for KVCACHED_POOL_IDLE_MS go back to the driver (PhysPool::decay)
+  // let handles that sat idle for KVCACHED_POOL_IDLE_MS go back to the driver (ExtentPool::decay), keep the reserve filled
   void housekeeping();
   // a thread that calls housekeeping() periodically exists / is gone (PageAllocator's watcher): while one does,
   // pools hand over-cap handles to it instead of releasing them on the caller's free() path
@@ -100,9 +101,12 @@ public:
   int64_t unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, int64_t *out_host, size_t cap,
                            hipStream_t s);
   // Make the driver invalidate this GPU's TLBs. hipMemMap/hipMemUnmap/hipMemSetAccess do not do it
-  // on ROCm 7.2 (stale translations survive a remap: kvcached_amd/csrc/tools/remap_diag.cpp), but
-  // the KFD map ioctl behind an ordinary >= 2 MiB hipMalloc does.
+  // on ROCm 7.2 (stale translations survive a remap: kvcached_amd/csrc/tools/remap_diag.cpp); KFD's unmap ioctl does:
+  // issued directly on a buffer of our own (KfdTlbFlush, drm_vm.hpp), or - where /dev/kfd cannot be used that way -
+  // through an ordinary >= 2 MiB hipMalloc + hipFree. KvAllocator::init proves on a scratch slot that whichever is
+  // in effect really invalidates, and refuses to start otherwise.
   void tlb_shootdown();
+  bool kfd_flush_active() const { return kfd_flush_.ready(); }
   // unmap path: the invalidation is owed but nothing needs it yet (see KvAllocator::unmap_slots)
   void defer_tlb_shootdown() { tlb_stale().store(true); }
   bool tlb_owed() const { return tlb_stale().load(); } // some unmap since the last invalidation (hip_vmm.hpp)
@@ -134,8 +138,9 @@ private:
   bool fl_stop_ = false, fl_kick_ = false;
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
-  std::unordered_map<size_t, std::unique_ptr<PhysPool>> pools_[2]; // key: granule (chunk pools: granule + 1)
-  std::unordered_map<size_t, std::unique_ptr<PiecePool>> piece_pools_[2];
+  std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
+  std::vector<ExtentPool *> all_pools();
+  KfdTlbFlush kfd_flush_;
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
   // unique_block_ids scratch (grow-only; bitmap all-zero and header reset between calls)

@@ -93,9 +93,9 @@ def test_backend_names_are_validated(monkeypatch):
     (no driver is touched), an unknown one is refused with the list."""
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setenv("KVCACHED_VMM_BACKEND", "cuda")
-    with pytest.raises(RuntimeError, match="'hip', 'hybrid', 'drm' or 'hsa'"):
+    with pytest.raises(RuntimeError, match="'drm', 'hybrid' or 'hip'"):
         vmm_ops.init_kvcached("cpu", 2 << 20, False)
-    for name in ("drm", "hybrid", "hip", "hsa"):
+    for name in ("drm", "hybrid", "hip"):
         monkeypatch.setenv("KVCACHED_VMM_BACKEND", name)
         vmm_ops.init_kvcached("cpu", 2 << 20, False)
         try:

@@ -285,8 +285,7 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
     the process (csrc/inc/gpu_vmm.hpp:37-45); here the batch is undone, alloc_page rolls the page id back
     (page_allocator.cpp:215-224 finally reachable), alloc() raises RuntimeError naming the page, and the very same
     allocation succeeds afterwards with the same block ids."""
-    if int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")) > 1:
-        pytest.skip("page-granular pool semantics; with chunked physical memory the fault-injection hook counts driver allocations, which are chunks then")
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "1")   # exact counts below: the injection hook counts driver allocations (one per page here)
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
@@ -332,8 +331,7 @@ def test_driver_failure_rolls_the_batch_back(monkeypatch):
 def test_shrinking_the_budget_releases_pooled_handles(monkeypatch):
     """`kvctl limit` semantics: a successful shrink gives memory back now — what the handle pool parked goes to the
     driver at once instead of waiting for the idle decay (the reference releases on every unmap)."""
-    if int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")) > 1:
-        pytest.skip("page-granular pool semantics; with chunked physical memory memory goes back to the driver by whole chunks then, and these 40 pages do not make up any")
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "1")   # page-granular counts (run-sized extents: the twin test below)
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
@@ -392,8 +390,7 @@ def test_pool_eviction_is_left_to_the_housekeeping_thread(monkeypatch):
     """With an allocator watcher thread around, handles that exceed the pool's cap are not released on the caller's
     free() path (hipMemRelease of a used handle is 40-50 us: 200 ms for a 4096-slot free) but by the 10 Hz
     housekeeping; without one (plain C-ABI use) the release stays immediate."""
-    if int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")) > 1:
-        pytest.skip("page-granular pool semantics; with chunked physical memory only whole chunks go back to the driver")
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "1")   # page-granular counts
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)

@@ -110,9 +110,9 @@ def test_prealloc_thread_invariants(cpu_ops):
     while pa.get_num_reserved_pages() < 5 and time.time() - t0 < 5:
         time.sleep(0.005)
     assert 5 <= pa.get_num_reserved_pages() <= 10
+    pa.stop_prealloc_thread()   # (a page the thread is moving from the free list to the reserved list is in neither for a moment)
+    pa.stop_prealloc_thread()
     assert sorted(pa._page_list(0) + pa._page_list(1) + held[25:]) == list(range(64))
-    pa.stop_prealloc_thread()
-    pa.stop_prealloc_thread()
     pa.free_pages(held[25:])
     assert pa.get_num_inuse_pages() == 0
     pa.start_prealloc_thread()
