@@ -57,9 +57,12 @@ def parse_args():
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", choices=["hip", "hybrid", "drm", "hsa"], default=os.environ.get("KVCACHED_VMM_BACKEND", "drm"),
+    ap.add_argument("--backend", choices=["hip", "hybrid", "drm"], default=os.environ.get("KVCACHED_VMM_BACKEND", "drm"),
                     help="VMM backend requested for the main measurement (library default: drm; DESIGN.md §4.6/§4.7); the line "
                          "reports the one in effect after the library's self tests")
+    ap.add_argument("--growth-burst-only", action="store_true",
+                    help="internal: run the growth burst (24 x 2 GiB backed, nothing unmapped) as the first GPU work of a "
+                         "fresh process and print its summary (the N=1 line's growth_burst_first_touch leg)")
     return ap.parse_args()
 
 
@@ -78,8 +81,7 @@ class Pool:
     def __init__(self, capi, device: str, window_batches: int, mode: str, pool_mb, page=PAGE, group_id=0,
                  compound_layers: int = 0, backend: str = "drm"):
         self.capi, self.device, self.window = capi, device, window_batches
-        os.environ["KVCACHED_VMM_BACKEND"] = "hsa" if backend.startswith("hsa") else backend
-        os.environ["KVCACHED_HSA_CPU_ACCESS"] = "false" if backend == "hsa_kernels_only" else "true"
+        os.environ["KVCACHED_VMM_BACKEND"] = backend
         os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
         if pool_mb is not None:
             os.environ["KVCACHED_PHYS_POOL_MB"] = str(pool_mb)
@@ -102,7 +104,6 @@ class Pool:
     def close(self):
         self.capi.shutdown()
         os.environ.pop("KVCACHED_VMM_BACKEND", None)
-        os.environ.pop("KVCACHED_HSA_CPU_ACCESS", None)
 
 
 def run_steps(capi, mapper, first_batch: int, n: int, slot: int = PAGE):
@@ -145,6 +146,7 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
             unmapper(offs)
         capi.set_option(capi.OPT_PROFILE, 1)
         capi.reset_stats()
+        c0 = [int(capi.get_option(k)) for k in (112, 113, 114, 115)]   # KFD alloc / export / DRM import ns, creations
         if barrier:
             barrier()
         if sync:
@@ -167,6 +169,11 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
             barrier()
         elapsed = time.perf_counter() - t0
         st = capi.get_stats()
+        c1 = [int(capi.get_option(k)) for k in (112, 113, 114, 115)]
+        n_created = c1[3] - c0[3]
+        create_split = ({"driver_allocations": n_created, "kfd_alloc_us": round((c1[0] - c0[0]) / n_created / 1e3, 2),
+                         "kfd_export_us": round((c1[1] - c0[1]) / n_created / 1e3, 2),
+                         "drm_import_us": round((c1[2] - c0[2]) / n_created / 1e3, 2)} if n_created else None)
         st["driver_ns"] = capi.get_driver_breakdown()
         capi.set_option(capi.OPT_PROFILE, 0)
         if burst:  # give everything back, outside the timed region
@@ -176,7 +183,9 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
                 per_unmap.append(time.perf_counter() - tb)
         return {"elapsed": elapsed, "per_step": per_map, "per_unmap": per_unmap, "stats": st, "reserve_s": pool.reserve_s,
                 "window_GiB": pool.size / GiB, "burst": burst,
-                "backend_in_effect": {0: "hip", 1: "hsa", 2: "hybrid", 3: "drm"}.get(int(capi.get_option(108)), "?")}
+                "backend_in_effect": {0: "hip", 2: "hybrid", 3: "drm"}.get(int(capi.get_option(108)), "?"),
+                "kfd_create": int(capi.get_option(110)), "kfd_tlb_flush": int(capi.get_option(118)),
+                "max_extent_pages": int(capi.get_option(119)), "create_split": create_split}
     finally:
         pool.close()
 
@@ -217,6 +226,9 @@ def roofline_from(st):
             traffic = None
     return {"kernel": "zero_fill_pages", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/zero_fill_traffic.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate passes over this "
+                              "same command (tools_gpu_round.sh), per launch, gfx950 unit corrections applied; not collected "
+                              "inside this run" if traffic is not None else None,
             "launches": launches, "bytes_per_launch": nbytes // launches,
             "avg_launch_us": round(ms / launches * 1e3, 2)}
 
@@ -414,6 +426,10 @@ def spawn_ranks(n: int) -> int:
     return (bad[0] if bad[0] > 0 else 1) if bad else 0
 
 
+def use_dist_requested() -> bool:
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("KVC_BENCH_FORCE_DIST") == "1"
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -445,6 +461,33 @@ def main():
         torch.cuda.set_device(local_rank)
         device = f"cuda:{local_rank}"
     from kvcached_amd import capi
+
+    if args.growth_burst_only:   # child of the N=1 run: the first GPU work of a fresh process
+        os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_gb_{os.getpid()}")
+        r1 = measure(capi, device, 24, 0, "lazy", None, burst=True, prefault=False, backend=args.backend)
+        s = summarize(r1, 24)
+        out = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k]) for k in
+               ("GBps", "p50_map_batch_ms", "map_us_per_page", "handles_created", "driver_us_per_page")}
+        out["create_split"] = r1.get("create_split")
+        out["per_batch_ms"] = [round(x * 1e3, 1) for x in r1["per_step"]]
+        print(json.dumps(out), flush=True)
+        return
+
+    # N = 1: before this process touches the GPU, a child runs the growth burst as the very first GPU work on the box -
+    # VRAM the kernel has not handed out since boot is cleared inside the allocation (~80 us per 2 MiB), memory that was
+    # wiped on release is not: the same burst later in this run (variants) shows the other side. DESIGN.md §4.5.
+    first_touch = None
+    if world == 1 and not rehearsal and not args.no_variants and not use_dist_requested():
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--growth-burst-only", "--backend", args.backend],
+                                 capture_output=True, text=True, timeout=300)
+            js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            first_touch = json.loads(js[-1]) if out.returncode == 0 and js else {"error": (out.stderr or out.stdout)[-300:]}
+            if "error" not in first_touch:
+                first_touch["what"] = ("24 x 1024 x 2 MiB backed with nothing unmapped, as the first GPU work of a fresh process on "
+                                       "this box: physical pages are allocated inside the timed region (create_split)")
+        except Exception as e:
+            first_touch = {"error": str(e)[:200]}
 
     fanout = barrier = None
     sync = None if rehearsal else torch.cuda.synchronize
@@ -496,7 +539,10 @@ def main():
             "ranks": ranks_seen,
             "config": {"workload": "bench_vmm: 64 GiB VA window (one untimed warm-up sweep over the window during set-up, as in "
                                    "the protocol); step = map+zero then unmap one batch of 1024 x 2 MiB "
-                                   "pages (shuffled offsets), both halves timed",
+                                   "pages (shuffled offsets), both halves timed. Physical pages are recycled through the "
+                                   "library's pool: the timed steps create none (handles_created) - allocation from the driver "
+                                   "is what growth_burst_* measure",
+                       "kfd_create": res["kfd_create"], "kfd_tlb_flush": res["kfd_tlb_flush"], "max_extent_pages": res["max_extent_pages"],
                        "mode": args.mode, "vmm_backend": res["backend_in_effect"] if not rehearsal else "none (cpu device)", "vmm_backend_requested": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
@@ -512,33 +558,36 @@ def main():
             "roofline": roofline_from(res["stats"]),
         }
         if world == 1 and not rehearsal:
+            if first_touch is not None:
+                line["growth_burst_first_touch"] = first_touch
             if not args.no_variants:
                 variants = {}
-                for name, mode, pool, comp, burst, pre in (
-                        ("physical_chunks_32MiB_opt_in", "lazy", None, 0, False, True),
-                        ("physical_chunks_8MiB_opt_in", "lazy", None, 0, False, True),
-                        ("unmap_waits_for_its_own_tlb_invalidation", "lazy", None, 0, False, True),
-                        ("hybrid_backend_same_cycle", "lazy", None, 0, False, True),
-                        ("hip_backend_same_cycle", "lazy", None, 0, False, True),
-                        ("hip_backend_compat_zero_backfill_sharded", "compat", None, 0, False, True),
-                        ("hsa_backend_cpu_accessible", "lazy", None, 0, False, True),
-                        ("hsa_backend_kernels_only", "lazy", None, 0, False, True),
-                        ("fresh_va_window_warm_process", "lazy", None, 0, False, False),
-                        ("growth_burst_24x2GiB_nothing_unmapped", "lazy", None, 0, True, False),   # growth = fresh VA, fresh handles
-                        ("no_pool_every_handle_created_and_released", "lazy", 0, 0, False, True),
-                        ("compat_zero_backfill_sharded", "compat", None, 0, False, True),
-                        ("page_size_8MiB_instead_of_2MiB", "lazy", None, 0, False, True),
-                        ("contiguous_layout_128MiB_compound_pages", "lazy", None, 32, False, True)):
+                # name -> (mode, pool cap MB, compound layers, burst, prefault, backend, page, extra environment, steps)
+                V = lambda mode="lazy", pool=None, comp=0, burst=False, pre=True, be=None, page=PAGE, env=None, n=24: \
+                    (mode, pool, comp, burst, pre, be or args.backend, page, env or {}, n)   # noqa: E731
+                table = {
+                    "one_buffer_per_page_round1_default": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "1"}),
+                    "extents_up_to_16_pages": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "16"}),
+                    "extents_up_to_64_pages": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "64"}),
+                    "unmap_waits_for_its_own_tlb_invalidation": V(env={"KVCACHED_ASYNC_SHOOTDOWN": "false"}),
+                    "tlb_flush_through_hipMalloc_instead_of_kfd": V(env={"KVCACHED_KFD_TLB_FLUSH": "false"}),
+                    "compat_zero_backfill_sharded": V(mode="compat", n=8),
+                    "hybrid_backend_same_cycle": V(be="hybrid"),
+                    "hip_backend_same_cycle": V(be="hip"),
+                    "hip_backend_compat_zero_backfill_sharded": V(mode="compat", be="hip", n=8),
+                    "fresh_va_window_warm_process": V(pre=False),
+                    "growth_burst_24x2GiB_nothing_unmapped": V(burst=True, pre=False),   # growth = fresh VA, fresh handles
+                    "growth_burst_one_buffer_per_page": V(burst=True, pre=False, env={"KVCACHED_PHYS_CHUNK_PAGES": "1"}),
+                    "no_pool_every_handle_created_and_released": V(pool=0, n=8),
+                    "page_size_8MiB_instead_of_2MiB": V(page=8 * MiB, n=8),
+                    "contiguous_layout_128MiB_compound_pages": V(comp=32, n=8),
+                }
+                for name, (mode, pool, comp, burst, pre, be, page, env, nsteps) in table.items():
+                    saved = {k: os.environ.get(k) for k in env}
                     try:
-                        if name.startswith("unmap_waits"):
-                            os.environ["KVCACHED_ASYNC_SHOOTDOWN"] = "false"
-                        if name.startswith("physical_chunks"):   # KVCACHED_PHYS_CHUNK_PAGES: DESIGN.md §4.8
-                            os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = "16" if "32MiB" in name else "4"
-                        nsteps = 24 if (burst or name.startswith(("fresh_va", "unmap_waits", "physical_chunks")) or name.endswith("_backend_same_cycle")) else 8
+                        os.environ.update(env)
                         r1 = measure(capi, device, nsteps, 4, mode, pool, compound_layers=comp, burst=burst, prefault=pre,
-                                     backend=("hsa_kernels_only" if "kernels_only" in name else "hsa") if name.startswith("hsa_")
-                                     else ("hip" if name.startswith("hip_") else ("hybrid" if name.startswith("hybrid_") else args.backend)),
-                                     page=8 * MiB if name.startswith("page_size_8MiB") else PAGE)
+                                     backend=be, page=page)
                         s = summarize(r1, nsteps)
                         variants[name] = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k])
                                           for k in ("GBps", "map_zero_GBps", "p50_map_batch_ms", "map_us_per_page",
@@ -546,12 +595,19 @@ def main():
                                                     "driver_us_per_page")}
                         rf = roofline_from(r1["stats"])
                         variants[name]["fill_GBps"] = rf["achieved"] if rf else None
+                        if r1.get("create_split"):
+                            variants[name]["create_split"] = r1["create_split"]
                     except Exception as e:
                         variants[name] = {"error": str(e)[:200]}
                     finally:
-                        os.environ.pop("KVCACHED_ASYNC_SHOOTDOWN", None)
-                        os.environ.pop("KVCACHED_PHYS_CHUNK_PAGES", None)
+                        for k, v in saved.items():
+                            if v is None:
+                                os.environ.pop(k, None)
+                            else:
+                                os.environ[k] = v
                 line["variants"] = variants
+                # the reference's semantics (unbacked VA reads as zeros) next to the headline, not only among the variants
+                line["compat_mode_GBps"] = variants.get("compat_zero_backfill_sharded", {}).get("GBps")
                 try:
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)
                 except Exception as e:

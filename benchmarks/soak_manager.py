@@ -30,7 +30,14 @@ def main():
     ap.add_argument("--prealloc", action="store_true", help="prealloc + watcher threads on")
     ap.add_argument("--page-ids", type=int, default=1024, help="virtual pool size in page ids (16 MiB each)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pool-mb", type=int, default=None, help="KVCACHED_PHYS_POOL_MB (0: every whole extent goes straight back "
+                    "to the driver, so that held/mapped shows fragmentation alone)")
+    ap.add_argument("--extent-pages", type=int, default=None, help="KVCACHED_PHYS_CHUNK_PAGES")
     args = ap.parse_args()
+    if args.pool_mb is not None:
+        os.environ["KVCACHED_PHYS_POOL_MB"] = str(args.pool_mb)
+    if args.extent_pages is not None:
+        os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = str(args.extent_pages)
     if args.backend:
         os.environ["KVCACHED_VMM_BACKEND"] = args.backend
     os.environ["KVCACHED_ASYNC_UNMAP"] = "true" if args.async_unmap else "false"
@@ -48,6 +55,7 @@ def main():
     torch.cuda.set_device(0)
     vmm_ops.init_kvcached(dev, PAGE, False)
     backend = {0: "hip", 2: "hybrid", 3: "drm"}[capi.get_option(108)]
+    max_extent_pages = int(capi.get_option(119)) if backend == "drm" and capi.get_option(110) else 1
     blocks_per_page = PAGE // BLOCK_BYTES
     num_blocks = args.page_ids * blocks_per_page
     per_layer = num_blocks * BLOCK_BYTES * 2                   # K half + V half
@@ -179,7 +187,7 @@ def main():
     fp = sorted(footprint) or [0.0]
     out = dict(held_over_mapped={"p50": round(fp[len(fp) // 2], 3), "p90": round(fp[int(len(fp) * 0.9)], 3), "max": round(fp[-1], 3),
                                  "what": "physical pages held from the driver (mapped + pooled + free pieces of partly used chunks) per mapped page"},
-               chunk_pages=int(os.environ.get("KVCACHED_PHYS_CHUNK_PAGES", "1")),
+               max_extent_pages=max_extent_pages, pool_mb=os.environ.get("KVCACHED_PHYS_POOL_MB", "default (16384)"),
                backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
                prealloc=args.prealloc, **counts, wrong_words=bad, inuse_pages_at_end=inuse,
                pages_mapped=st["pages_mapped"], pages_unmapped=st["pages_unmapped"],

@@ -102,6 +102,56 @@ def test_map_gives_private_zeroed_pages_even_when_recycled(vmm):
     assert ops.unmap_from_kv_tensors([PAGE, 2 * PAGE, 4 * PAGE])
 
 
+_CONFIGS = [(b, mode, au, ck) for b in ("drm", "hybrid", "hip") for mode in ("lazy", "compat") for au in (0, 1)
+            for ck in ((1, 32) if b == "drm" else (1,)) if not (mode == "compat" and au)]   # async unmap is ignored in compat mode
+
+
+@pytest.mark.parametrize("backend,mode,async_unmap,extent_pages", _CONFIGS)
+def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkeypatch, backend, mode, async_unmap, extent_pages):
+    """The stale-translation / recycled-page property over every combination that ships: VMM backend x lazy|compat x
+    synchronous|queued unmaps x single-page|run-sized extents. Each round backs a random set of slots (they must read
+    zero - never the page's or the slot's previous contents), stamps them, takes a random subset away again (in compat
+    mode those must read zero at once: back on a zero alias) and checks every survivor, i.e. pages whose neighbours were
+    just unmapped, re-aliased or re-backed."""
+    import random
+    monkeypatch.setenv("KVCACHED_VMM_BACKEND", backend)
+    monkeypatch.setenv("KVCACHED_ASYNC_UNMAP", "true" if async_unmap else "false")
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", str(extent_pages))
+    ops, capi, ts = _setup(vmm, layers=2, per_layer=64 * PAGE, backfill=(mode == "compat"), kv=1, unified=False)
+    want_backend = {"drm": 3, "hybrid": 2, "hip": 0}[backend]
+    assert capi.get_option(108) == want_backend
+    assert capi.get_option(capi.OPT_ASYNC_UNMAP) == async_unmap
+    n, epp = 64, PAGE // 2
+    rng = random.Random(hash((backend, mode, async_unmap, extent_pages)) & 0xffff)
+    stamp, serial = {}, 0
+    for rnd in range(8):
+        free = [i for i in range(n) if i not in stamp]
+        want = rng.sample(free, rng.randint(1, len(free)))
+        assert ops.map_to_kv_tensors([i * PAGE for i in want])
+        for i in want:
+            serial += 1
+            for t in ts:
+                assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0, (rnd, i)
+                t[i * epp:(i + 1) * epp] = serial
+            stamp[i] = serial
+        torch.cuda.synchronize()
+        victims = rng.sample(sorted(stamp), rng.randint(1, max(1, len(stamp) * 2 // 3)))
+        assert ops.unmap_from_kv_tensors([i * PAGE for i in victims])
+        for i in victims:
+            stamp.pop(i)
+            if mode == "compat":
+                for t in ts:
+                    assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0, (rnd, i)
+        for i, v in stamp.items():
+            for t in ts:
+                assert bool((t[i * epp:(i + 1) * epp] == v).all()), (rnd, i, v)
+    assert ops.unmap_from_kv_tensors([i * PAGE for i in sorted(stamp)])
+    capi.flush_unmaps()
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_double_map_and_unmapped_unmap_are_tolerated_like_the_reference(vmm):
     ops, capi, ts = _setup(vmm)
     assert ops.map_to_kv_tensors([0])
@@ -328,17 +378,20 @@ def test_process_exit_without_shutdown_is_clean(backend):
     assert "leaving without shutdown_kvcached" in r.stdout
 
 
-def test_chunked_physical_memory_opt_in(vmm, monkeypatch):
-    """KVCACHED_PHYS_CHUNK_PAGES=16: physical memory in 32 MiB chunks, page-sized pieces mapped at
-    offsets, runs of adjacent slots in one ioctl. The hazard this mode has to handle: pages taken out of the middle of a
-    multi-page mapping leave neighbours whose page-table entries still claim the old extent - a slot backed afresh
-    would show its previous page. Seeded churn over two regions with every slot stamped and checked, neighbours read
-    in between; then the ledger: whole chunks only, nothing leaked."""
+@pytest.mark.parametrize("max_pages", [16, 64])
+def test_run_sized_extents_keep_every_page_with_its_slot(vmm, monkeypatch, max_pages):
+    """Run-sized physical extents (the default with the drm backend): a run of adjacent slots is backed
+    by ONE buffer and mapped with one ioctl; single pages are mapped at an offset into it. The hazard this has to
+    handle: pages taken out of the middle of a multi-page mapping leave neighbours whose page-table entries still claim
+    the old extent - a slot backed afresh would show its previous page. Seeded churn over two regions with every slot
+    stamped and checked, neighbours read in between; then the ledger: nothing leaked, and the pool's own accounting
+    (held = handed out + idle + free pieces) agrees with the driver-side counters."""
     import random
-    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "16")
+    monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", str(max_pages))
     ops, capi, ts = _setup(vmm, layers=2, per_layer=192 * MiB, backfill=False, kv=1, unified=False)
     if capi.get_option(108) != 3 or capi.get_option(110) != 1:
         pytest.skip("needs the drm backend with pages straight from KFD")
+    assert capi.get_option(capi.OPT_MAX_EXTENT_PAGES) == max_pages
     capi.reset_stats()
     n, epp = 96, PAGE // 2
     rng = random.Random(11)
@@ -368,13 +421,122 @@ def test_chunked_physical_memory_opt_in(vmm, monkeypatch):
         for i in victims:
             stamp.pop(i)
         check_all()                                                    # the survivors, right after their mappings were split
+        held, out, waste = (capi.get_option(k) for k in (capi.OPT_POOL_HELD_PAGES, capi.OPT_POOL_OUT_PAGES, capi.OPT_POOL_FREE_PIECES))
+        st = capi.get_stats()
+        assert out == 2 * len(stamp) and held == st["handles_created"] - st["handles_released"] and held >= out + waste
     st = capi.get_stats()
-    assert st["handles_created"] % 16 == 0 and st["handles_created"] >= 2 * 16       # counted in pages, made in chunks
-    assert st["handles_reused"] < st["pages_mapped"] <= st["handles_created"] + st["handles_reused"]
+    assert st["pages_mapped"] <= st["handles_created"] + st["handles_reused"]
+    assert st["handles_created"] < st["pages_mapped"]                  # pieces and whole extents were reused
     assert ops.unmap_from_kv_tensors([i * PAGE for i in sorted(stamp)])
     ops.shutdown_kvcached()
     st = capi.get_stats()
     assert st["handles_created"] == st["handles_released"]
+
+
+def test_a_batch_of_adjacent_slots_is_a_handful_of_ioctls(vmm):
+    """The point of extents: 1024 adjacent 2 MiB slots are backed by 1024 / 32 buffers, mapped with as many ioctls and
+    dropped with as many - against 1024 + 1024 with one buffer per page - and the same extents serve the next batch."""
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=4096 * PAGE, backfill=False, kv=1, unified=True)
+    if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+        pytest.skip("needs the drm backend with pages straight from KFD")
+    k = capi.get_option(capi.OPT_MAX_EXTENT_PAGES)
+    assert k > 1
+    import random
+    offs = [i * PAGE for i in range(1024)]
+    random.Random(0).shuffle(offs)                                      # the order the caller lists them in does not matter
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors(offs)
+    st = capi.get_stats()
+    assert st["handles_created"] == 1024 and capi.get_option(capi.OPT_POOL_FREE_PIECES) == 0
+    creates = capi.get_option(115)
+    t = ts[0]
+    assert int(torch.count_nonzero(t[:1024 * PAGE // 2])) == 0
+    t[:1024 * PAGE // 2] = 7
+    torch.cuda.synchronize()
+    assert ops.unmap_from_kv_tensors(offs)
+    capi.reset_stats()
+    offs2 = [(2048 + i) * PAGE for i in range(1024)]                   # other slots, the same physical extents
+    assert ops.map_to_kv_tensors(offs2)
+    st = capi.get_stats()
+    assert st["handles_created"] == 0 and st["handles_reused"] == 1024
+    assert capi.get_option(115) == creates                             # not one driver allocation
+    assert int(torch.count_nonzero(t[2048 * PAGE // 2:3072 * PAGE // 2])) == 0    # recycled, dirty, zero again
+    assert ops.unmap_from_kv_tensors(offs2)
+
+
+_TLB_CHILD = r"""
+import os, sys
+sys.path.insert(0, %r)
+from kvcached_amd import capi, vmm_ops
+try:
+    vmm_ops.init_kvcached("cuda:0", 2 << 20, False)
+except RuntimeError as e:
+    print("INIT REFUSED:", e)
+    sys.exit(0)
+print("INIT OK backend", capi.get_option(108), "kfd flush", capi.get_option(118))
+vmm_ops.shutdown_kvcached()
+"""
+
+
+@pytest.mark.parametrize("backend", ["drm", "hybrid", "hip"])
+def test_init_refuses_to_start_when_tlb_invalidation_is_ineffective(backend):
+    """Page privacy rests on the TLB invalidation after unmaps. init proves on a scratch slot - two pages
+    swapped under one VA, written and read through the GPU's own translation - that the invalidation in effect works,
+    with whatever backend is left standing after the fallback chain; when it does not (here: a hook turns the flush into
+    a no-op, as a runtime that stopped flushing would) the library refuses to serve a single page."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, KVCACHED_VMM_BACKEND=backend, KVCACHED_LOG_LEVEL="ERROR")
+    ok = subprocess.run([sys.executable, "-c", _TLB_CHILD % repo], env=base, capture_output=True, text=True, timeout=240)
+    assert ok.returncode == 0 and "INIT OK" in ok.stdout, (ok.stdout, ok.stderr[-800:])
+    broken = subprocess.run([sys.executable, "-c", _TLB_CHILD % repo], env=dict(base, KVCACHED_TEST_BREAK_TLB_FLUSH="1"),
+                            capture_output=True, text=True, timeout=240)
+    assert broken.returncode == 0, broken.stderr[-800:]
+    assert "INIT REFUSED" in broken.stdout and "TLB invalidation is ineffective" in broken.stdout, broken.stdout
+
+
+def test_tlb_invalidation_goes_straight_to_kfd(vmm, monkeypatch):
+    """The default trigger is the KFD map/unmap ioctl pair on the library's own buffer (no user-space cache can answer
+    it); KVCACHED_KFD_TLB_FLUSH=false keeps the hipMalloc+hipFree path, and privacy holds with either."""
+    epp = PAGE // 2
+    for use_kfd in (True, False):
+        monkeypatch.setenv("KVCACHED_KFD_TLB_FLUSH", "true" if use_kfd else "false")
+        # the flush object belongs to the per-device context, which shutdown destroys: a fresh init re-reads the switch
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * PAGE, backfill=False, kv=1, unified=True)
+        assert capi.get_option(capi.OPT_KFD_TLB_FLUSH_ACTIVE) == int(use_kfd)
+        t = ts[0]
+        for rnd in range(4):
+            offs = [((rnd * 5 + i * 3) % 64) * PAGE for i in range(16)]
+            offs = sorted(set(offs))
+            assert ops.map_to_kv_tensors(offs)
+            for o in offs:
+                assert int(torch.count_nonzero(t[o // 2:o // 2 + epp])) == 0
+                t[o // 2:o // 2 + epp] = rnd + 1
+            torch.cuda.synchronize()
+            assert ops.unmap_from_kv_tensors(offs)
+        st = capi.get_stats()
+        assert st["tlb_shootdowns"] >= 1
+        ops.shutdown_kvcached()
+
+
+def test_a_second_init_for_another_device_is_refused_while_kv_tensors_exist(vmm):
+    """One device per process, as in the reference (one FTensorAllocator, csrc/allocator.cpp:18-22): pooled pages and the
+    driver handles behind them belong to the device of the first init."""
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=8 * PAGE, backfill=False, kv=1, unified=True)
+    assert ops.map_to_kv_tensors([0])
+    ts[0][:16] = 3
+    with pytest.raises(RuntimeError, match="one device per process"):
+        ops.init_kvcached("cpu", PAGE, False)
+    if torch.cuda.device_count() > 1:
+        with pytest.raises(RuntimeError, match="one device per process"):
+            ops.init_kvcached("cuda:1", PAGE, False)
+    assert bool((ts[0][:16] == 3).all())                                # nothing was torn down
+    assert ops.unmap_from_kv_tensors([0])
+    ops.init_kvcached(DEV, PAGE, False)                                 # the same device: re-created like the reference
+    ops.shutdown_kvcached()
+    ops.init_kvcached("cpu", PAGE, False)                               # after a shutdown any device goes
+    ops.shutdown_kvcached()
 
 
 def test_reinit_never_writes_through_a_translation_of_a_previous_life(vmm):
