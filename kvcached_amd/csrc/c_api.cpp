@@ -179,6 +179,10 @@ int64_t kvc_get_option(int opt) {
     GpuContext *ctx = KvAllocator::gpu();
     return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().extent_pages_now : 0;
   }
+  case 124: { // releases of pieces the pool did not know (must stay 0; read-only)
+    GpuContext *ctx = KvAllocator::gpu();
+    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().bad_releases : 0;
+  }
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;
   case 101: return options().compact_variant;

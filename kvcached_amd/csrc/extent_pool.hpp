@@ -30,6 +30,7 @@
 #include <functional>
 #include <mutex>
 #include <set>
+#include <stdexcept>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -39,17 +40,21 @@ namespace kvc {
 using phys_handle_t = uint64_t; // hipMemGenericAllocationHandle_t (a pointer), hsa_amd_vmem_alloc_handle_t::handle, or
                                 // (drm backend, pages allocated straight from KFD) KFD's buffer handle
 
-// A handle names ONE page-sized piece of an extent: the extent's buffer handle (KFD handles and user-space pointers are
-// < 2^48) with the extent's size - 1 in bits 48-55 and the piece index in the top byte. For a one-page extent - every
-// backend but drm, and single slots there - a piece id IS the buffer handle.
+// A handle names ONE page-sized piece of an extent. For a one-page extent - every backend but drm, and single slots there -
+// the piece id IS the buffer handle, untouched (ROCr's handles use bits above 48: nothing is ever masked out of them).
+// A piece of a multi-page extent - those are KFD buffer handles, (gpu_id << 32 | idr) < 2^48 - is tagged with bit 63 and
+// carries the extent's size - 1 in bits 48-55 and the piece index in bits 56-62.
 constexpr int kPieceShift = 56, kPagesShift = 48;
+constexpr uint64_t kPieceTag = 1ull << 63;
 constexpr unsigned kMaxExtentPages = 64; // pieces of an extent are tracked in one 64-bit mask
+inline bool is_piece(phys_handle_t h) { return (h & kPieceTag) != 0; }
 inline phys_handle_t piece_id(phys_handle_t extent, unsigned piece, unsigned pages = 1) {
-  return extent | (static_cast<uint64_t>(pages - 1) << kPagesShift) | (static_cast<uint64_t>(piece) << kPieceShift);
+  if (pages <= 1) return extent;
+  return extent | kPieceTag | (static_cast<uint64_t>(pages - 1) << kPagesShift) | (static_cast<uint64_t>(piece) << kPieceShift);
 }
-inline phys_handle_t chunk_of(phys_handle_t h) { return h & ((1ull << kPagesShift) - 1); }
-inline unsigned piece_of(phys_handle_t h) { return static_cast<unsigned>(h >> kPieceShift); }
-inline unsigned pages_of(phys_handle_t h) { return static_cast<unsigned>((h >> kPagesShift) & 0xff) + 1; }
+inline phys_handle_t chunk_of(phys_handle_t h) { return is_piece(h) ? (h & ((1ull << kPagesShift) - 1)) : h; }
+inline unsigned piece_of(phys_handle_t h) { return is_piece(h) ? static_cast<unsigned>((h >> kPieceShift) & 0x7f) : 0; }
+inline unsigned pages_of(phys_handle_t h) { return is_piece(h) ? static_cast<unsigned>((h >> kPagesShift) & 0xff) + 1 : 1; }
 
 struct VmmCounters { // in pages
   std::atomic<int64_t> created{0}, released{0}, reused{0};
@@ -116,6 +121,11 @@ public:
     lk.unlock();
     const phys_handle_t h = drv_.create(n); // may throw: nothing of ours has changed yet
     lk.lock();
+    if (n > 1 && (h >> kPagesShift) != 0) { // cannot be told apart from a piece id: never happens with KFD handles
+      lk.unlock();
+      (void)drv_.release(h);
+      throw std::runtime_error("extent pool: a multi-page buffer handle does not fit 48 bits");
+    }
     Extent &e = tracked_[h];
     e.seq = ++next_seq_;
     e.n = (uint8_t)n;

@@ -1416,7 +1416,8 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
 // (drm backend: one GEM_VA ioctl; else map + one set_access per contiguous run); zero_fill_pages launches that run on
 // the GPU while the host keeps issuing driver calls for the next slots (3/4 of the batch, then the rest); a TLB
 // invalidation before the first fill only if one is owed; one stream sync at the end.
-void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported) {
+void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported,
+                            std::vector<uint8_t> *imported_consumed) {
   if (slots.empty()) return;
   if (!dev_.is_gpu) { // reference CPUPage::map is a no-op (page.cpp:34-37); keep the double-map diagnostics
     for (auto &s : slots) {
@@ -1530,7 +1531,9 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       int64_t t1 = now_ns();
       bool recycled = false;
       Phys ph;
+      size_t import_index = 0;
       if (imported) {
+        import_index = next_import;
         ph = Phys{(*imported)[next_import++], 0};
       } else if (chunked && !r.backfilled) {
         fresh.push_back(s); // backed below, run by run: adjacent slots share one ioctl
@@ -1561,6 +1564,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       r.handle[s.index] = h;
       r.seq[s.index] = ph.seq;
       r.mapped[s.index] = imported ? 2 : 1;
+      if (imported && imported_consumed) (*imported_consumed)[import_index] = 1; // the slot owns it now (rollback releases it)
       done.push_back(s);
       if (!needs_access) { // mapped readable+writable in one ioctl (drm backend): straight to the fill queue
         if (always_flush) dirty_tlb = true;
@@ -1824,8 +1828,19 @@ std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by 
 }
 static phys_handle_t import_posix_fd(int fd) {
   if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
-  if (vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && env_bool("KVCACHED_DRM_KFD_IMPORT", true))
-    return DrmVm::instance().import_fd(fd); // straight into KFD + DRM: mapped with one ioctl like our own pages
+  if (vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && env_bool("KVCACHED_DRM_KFD_IMPORT", true)) {
+    // straight into KFD + DRM: mapped with one ioctl like our own pages. A buffer that lives on ANOTHER GPU (rank 0's
+    // pages seen from a peer over xGMI) may be refused by this shortcut - ROCr's import, which sets up peer access for
+    // the local agent, is the fallback (hsa_amd_vmem_import_shareable_handle + map + set_access below).
+    try {
+      if (env_bool("KVCACHED_TEST_FAIL_KFD_IMPORT", false)) throw GpuError("AMDKFD_IOC_IMPORT_DMABUF failed [injected]");
+      return DrmVm::instance().import_fd(fd);
+    } catch (const GpuError &e) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true))
+        KVC_LOG(LOG_WARNING, "direct import of a shared page failed (%s): importing through ROCr from now on", e.what());
+    }
+  }
   if (vmm_uses_rocr()) { // ROCr takes the dmabuf fd by value
     hsa_amd_vmem_alloc_handle_t hh{};
     HSA_CHECK(hsa_amd_vmem_import_shareable_handle(fd, &hh));
@@ -1860,17 +1875,23 @@ int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out
   auto slots = slots_for(offsets, n);
   if ((int64_t)slots.size() > cap) return (int)slots.size();
   ctx_->bind();
-  int k = 0;
-  for (auto &s : slots) {
+  for (auto &s : slots) // nothing is exported unless everything can be
     if (s.region->mapped[s.index] != 1) throw InvalidError("export of a slot that is not backed by a local page");
-    int fd = -1;
-    if (vmm_uses_rocr()) {
-      if (vmm_backend() == kVmmDrm) fd = DrmVm::instance().export_fd(s.region->handle[s.index]); // -1: a ROCr handle
-      if (fd < 0) HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
-    } else {
-      HIP_CHECK(hipMemExportToShareableHandle(&fd, as_hip(s.region->handle[s.index]), hipMemHandleTypePosixFileDescriptor, 0));
+  int k = 0;
+  try {
+    for (auto &s : slots) {
+      int fd = -1;
+      if (vmm_uses_rocr()) {
+        if (vmm_backend() == kVmmDrm) fd = DrmVm::instance().export_fd(s.region->handle[s.index]); // -1: a ROCr handle
+        if (fd < 0) HSA_CHECK(hsa_amd_vmem_export_shareable_handle(&fd, as_hsa(s.region->handle[s.index]), 0));
+      } else {
+        HIP_CHECK(hipMemExportToShareableHandle(&fd, as_hip(s.region->handle[s.index]), hipMemHandleTypePosixFileDescriptor, 0));
+      }
+      out_fds[k++] = fd;
     }
-    out_fds[k++] = fd;
+  } catch (...) { // the caller never learns how many were written: close them here
+    for (int i = 0; i < k; ++i) ::close(out_fds[i]);
+    throw;
   }
   return k;
 }
@@ -1890,7 +1911,19 @@ bool KvAllocator::map_imported_slots(const offset_t *offsets, size_t n, const in
     for (size_t j = 0; j < i; ++j) (void)vmm_try_release(hs[j]);
     throw;
   }
-  map_slots(slots, &hs);
+  // map_slots consumes the handles of the slots it backs (they are released again by its own rollback if the batch
+  // fails); what it skips - a slot that is already mapped - or never reaches must not stay imported: every such
+  // handle pins a page of the peer's pool for the life of this process.
+  std::vector<uint8_t> consumed(n_fds, 0);
+  try {
+    map_slots(slots, &hs, &consumed);
+  } catch (...) {
+    for (size_t j = 0; j < n_fds; ++j)
+      if (!consumed[j]) (void)vmm_try_release(hs[j]);
+    throw;
+  }
+  for (size_t j = 0; j < n_fds; ++j)
+    if (!consumed[j]) (void)vmm_try_release(hs[j]);
   return true;
 }
 

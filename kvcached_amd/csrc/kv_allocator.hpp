@@ -225,7 +225,10 @@ private:
   void backfill_all(KvRegion &r);
   void register_slot(KvRegion &r, size_t slot);   // hybrid backend: make HIP aware of the slot's VA (once per slot)
   void unregister_slots(KvRegion &r);             // ... and take that back before the VA range is freed
-  void map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported);
+  // `imported`: a peer's pages, one per slot, instead of pages from the pool; imported_consumed[i] is set for every
+  // handle a slot took ownership of (the caller releases the others)
+  void map_slots(const std::vector<Slot> &slots, const std::vector<phys_handle_t> *imported,
+                 std::vector<uint8_t> *imported_consumed = nullptr);
   void unmap_slots(const std::vector<Slot> &slots);
   // the two halves of unmap_slots: driver unmaps under mu_ (handles collected), then invalidate + give handles back
   struct Unmapped {

@@ -16,6 +16,13 @@ worker listener :96-145, broadcast_* wrappers :250-267), two transports:
    (RCCL over xGMI on GPUs, gloo in the CPU tests), every rank maps locally, one all-reduce(min)
    collects the status. Payloads are < 10 KB: latency-bound, not link-bound.
 
+Engine wiring of (2) - KVCACHED_TP_TRANSPORT=collective: the scheduler of vLLM V1 lives outside the workers' process
+group, so `broadcast_*` (unchanged names and signatures) make ONE Unix hop to rank 0's listener, and rank 0 relays the
+command to its TP group with CollectiveFanout (`start_collective_worker()` on every worker, next to
+`start_worker_listener_thread()`): one RCCL broadcast + one status all-reduce instead of tp_size socket round trips
+(reference dispatch: csrc/page_allocator.cpp:633-635 -> kvcached/tp_ipc_util.py:173-192 -> worker loop :96-145).
+KVCACHED_SHARED_POOL=1 on top: rank 0 backs the slots and ships its pages to the peers (`share_mapped_slots`).
+
 Shared physical pool (north-star addition, `send_fds`/`recv_fds`): rank 0 exports one POSIX fd per
 backed slot (hipMemExportToShareableHandle) and ships them with SCM_RIGHTS over the same Unix
 sockets — fds cannot travel through RCCL; peers import and map them.
@@ -116,9 +123,44 @@ def recv_fds(sock: socket.socket, n_fds: int) -> Tuple[Message, List[int]]:
 
 
 # ------------------------------------------------------------------ worker side
+def tp_transport() -> str:
+    """"unix" (default; the reference's shape: the scheduler talks to every rank's socket) or "collective" (scheduler ->
+    rank 0 over its socket, rank 0 -> TP group over torch.distributed). Read at call time: tests flip it."""
+    t = os.environ.get("KVCACHED_TP_TRANSPORT", "unix").lower()
+    if t not in ("unix", "collective"):
+        raise ValueError("KVCACHED_TP_TRANSPORT must be 'unix' or 'collective'")
+    return t
+
+
+def shared_pool_enabled() -> bool:
+    return os.environ.get("KVCACHED_SHARED_POOL", "0").lower() in ("1", "true", "yes", "on")
+
+
+_collective: Optional["CollectiveFanout"] = None   # this worker's relay (the src rank of its TP group holds it)
+_collective_lock = threading.Lock()
+_follower: Optional[threading.Thread] = None
+
+
 def _execute(msg: Message) -> Message:
     group_id: int = msg.get("group_id", 0)
     cmd = msg["cmd"]
+    if msg.get("relay"):   # KVCACHED_TP_TRANSPORT=collective: this rank passes the command on to its TP group
+        fan = _collective
+        if fan is None:
+            return {"status": "error", "message": "relay requested but start_collective_worker() has not run on this rank"}
+        code = {"map_to_kv_tensors": CMD_MAP, "unmap_from_kv_tensors": CMD_UNMAP, "kv_tensors_created": CMD_CREATED}.get(cmd)
+        if code is None:
+            return {"status": "error", "message": "Unknown command"}
+        with _collective_lock:
+            if code == CMD_MAP and msg.get("shared_pool"):
+                # rank 0 backs the slots with its own (exportable) pages, every peer maps those very pages
+                map_to_kv_tensors(msg["offsets"], group_id=group_id)
+                share_mapped_slots(fan.world_size, msg["offsets"], msg.get("pp_rank", 0), group_id, src_rank=fan.rank)
+                return {"status": "success"}
+            ok = fan.run(code, msg.get("offsets", ()), group_id, raise_on_failure=False)
+        if code == CMD_CREATED:
+            return {"status": "success", "created": ok}
+        return {"status": "success"} if ok else {"status": "error", "message": "a tensor-parallel rank failed to " + cmd}
     if cmd == "map_to_kv_tensors":
         map_to_kv_tensors(msg["offsets"], group_id=group_id)
         return {"status": "success"}
@@ -128,6 +170,35 @@ def _execute(msg: Message) -> Message:
     if cmd == "kv_tensors_created":
         return {"status": "success", "created": bool(kv_tensors_created(group_id=group_id))}
     return {"status": "error", "message": "Unknown command"}
+
+
+def start_collective_worker(group=None, src: int = 0, device: Optional[str] = None) -> "CollectiveFanout":
+    """Every TP worker calls this once torch.distributed is up (KVCACHED_TP_TRANSPORT=collective). `group` should be a
+    group of its own (dist.new_group over the TP ranks): its collectives are issued from helper threads and must not
+    interleave with the engine's. The src rank keeps the fan-out for its socket listener to relay with; every other
+    rank parks a daemon thread in the collective, applying what src broadcasts, until stop_collective_worker()."""
+    global _collective, _follower
+    fan = CollectiveFanout(group=group, src=src, device=device)
+    if fan.rank == src:
+        _collective = fan
+    else:
+        def follow():
+            while fan.serve_one():
+                pass
+        _follower = threading.Thread(target=follow, name="kvcached-tp-follower", daemon=True)
+        _follower.start()
+    return fan
+
+
+def stop_collective_worker(timeout: float = 10.0) -> None:
+    """src rank: releases the followers (one last broadcast). Other ranks: wait for the follower thread to leave."""
+    global _collective
+    fan, _collective = _collective, None
+    if fan is not None:
+        with _collective_lock:
+            fan.run(CMD_STOP, (), 0, raise_on_failure=False)
+    if _follower is not None:
+        _follower.join(timeout)
 
 
 def _serve_connection(rank: int, conn: socket.socket) -> None:
@@ -148,6 +219,9 @@ def _serve_connection(rank: int, conn: socket.socket) -> None:
                         for fd in fds:
                             os.close(fd)
                     reply: Message = {"status": "success"}
+                elif msg.get("cmd") == "share_mapped_slots":  # shared pool, unix transport: this rank ships its pages
+                    share_mapped_slots(msg["tp_size"], msg["offsets"], msg.get("pp_rank", 0), msg.get("group_id", 0), src_rank=rank)
+                    reply = {"status": "success"}
                 else:
                     reply = _execute(msg)
             except Exception as e:
@@ -208,31 +282,43 @@ class _Channels:
             except OSError:
                 pass
 
-    def request_all(self, tp_size: int, pp_rank: int, msg: Message, what: str) -> List[Message]:
-        """Write `msg` to every rank, then collect every reply; one reconnect attempt per rank."""
+    def request_all(self, tp_size: int, pp_rank: int, msg: Message, what: str, ranks: Optional[Sequence[int]] = None) -> List[Message]:
+        """Write `msg` to every rank (or to `ranks`), then collect every reply; one reconnect attempt per rank.
+        The connections are persistent, so a reply left unread would be taken for the answer to the NEXT request: every
+        rank that was written to is read, whatever the others answered, and a rank whose exchange broke is dropped
+        (reconnected next time) - then the first failure is raised."""
         data = pickle.dumps(msg)
         frame = len(data).to_bytes(4, 'big') + data
         with self._lock:
-            keys = [(r, pp_rank) for r in range(tp_size)]
+            keys = [(r, pp_rank) for r in (range(tp_size) if ranks is None else ranks)]
+            sent: List[Tuple[int, int]] = []
+            failure: Optional[str] = None
             for key in keys:
                 for attempt in (0, 1):
                     try:
                         (self._socks.get(key) or self._connect(key)).sendall(frame)
+                        sent.append(key)
                         break
                     except OSError as e:
                         self.drop(key)
                         if attempt:
-                            raise RuntimeError(f"Worker {key[0]} failed to {what}: {e}")
+                            failure = failure or f"Worker {key[0]} failed to {what}: {e}"
+                if failure:
+                    break   # the ranks already written to still answer below
             replies: List[Message] = []
-            for key in keys:
+            for key in sent:
                 try:
                     reply = recv_msg(self._socks[key])
                 except Exception as e:
                     self.drop(key)
-                    raise RuntimeError(f"Worker {key[0]} failed to {what}: {e}")
+                    failure = failure or f"Worker {key[0]} failed to {what}: {e}"
+                    continue
                 if not isinstance(reply, dict) or reply.get("status") != "success":
-                    raise RuntimeError(f"Worker {key[0]} failed to {what}: {reply}")
+                    failure = failure or f"Worker {key[0]} failed to {what}: {reply}"
+                    continue
                 replies.append(reply)
+            if failure:
+                raise RuntimeError(failure)
             return replies
 
     def close(self) -> None:
@@ -244,19 +330,31 @@ class _Channels:
 _channels = _Channels()
 
 
+def _fan_out(tp_size: int, pp_rank: int, msg: Message, what: str) -> List[Message]:
+    if tp_transport() == "collective":   # one hop to rank 0, which relays to its TP group (RCCL broadcast + status all-reduce)
+        return _channels.request_all(tp_size, pp_rank, dict(msg, relay=True, pp_rank=pp_rank), what, ranks=(0,))
+    return _channels.request_all(tp_size, pp_rank, msg, what)
+
+
 def broadcast_map_to_kv_tensors(tp_size: int, offsets: List[int], pp_rank: int = 0, group_id: int = 0) -> None:
-    _channels.request_all(tp_size, pp_rank, {"cmd": "map_to_kv_tensors", "offsets": list(offsets),
-                                             "group_id": group_id}, "map")
+    msg: Message = {"cmd": "map_to_kv_tensors", "offsets": list(offsets), "group_id": group_id}
+    if shared_pool_enabled():
+        if tp_transport() == "collective":   # rank 0 backs and ships its pages to the peers itself
+            _fan_out(tp_size, pp_rank, dict(msg, shared_pool=True), "map")
+        else:                                  # rank 0 backs, then this process asks it to share
+            _channels.request_all(tp_size, pp_rank, msg, "map", ranks=(0,))
+            _channels.request_all(tp_size, pp_rank, dict(msg, cmd="share_mapped_slots", tp_size=tp_size, pp_rank=pp_rank),
+                                  "share mapped slots", ranks=(0,))
+        return
+    _fan_out(tp_size, pp_rank, msg, "map")
 
 
 def broadcast_unmap_from_kv_tensors(tp_size: int, offsets: List[int], pp_rank: int = 0, group_id: int = 0) -> None:
-    _channels.request_all(tp_size, pp_rank, {"cmd": "unmap_from_kv_tensors", "offsets": list(offsets),
-                                             "group_id": group_id}, "unmap")
+    _fan_out(tp_size, pp_rank, {"cmd": "unmap_from_kv_tensors", "offsets": list(offsets), "group_id": group_id}, "unmap")
 
 
 def broadcast_kv_tensors_created(tp_size: int, pp_rank: int = 0, group_id: int = 0) -> bool:
-    replies = _channels.request_all(tp_size, pp_rank, {"cmd": "kv_tensors_created", "group_id": group_id},
-                                    "check KV tensors created")
+    replies = _fan_out(tp_size, pp_rank, {"cmd": "kv_tensors_created", "group_id": group_id}, "check KV tensors created")
     return all(r.get("created", False) for r in replies)
 
 
@@ -270,21 +368,35 @@ def share_mapped_slots(tp_size: int, offsets: List[int], pp_rank: int = 0, group
         msg = {"cmd": "map_imported_slots", "offsets": list(offsets), "group_id": group_id, "n_fds": len(fds)}
         with _channels._lock:
             peers = [(r, pp_rank) for r in range(tp_size) if r != src_rank]
+            sent, failure = [], None
             for key in peers:
-                s = _channels._socks.get(key) or _channels._connect(key)
-                send_msg(s, msg)
-                send_fds(s, {"fds": len(fds)}, fds)
-            for key in peers:
-                reply = recv_msg(_channels._socks[key])
+                try:
+                    s = _channels._socks.get(key) or _channels._connect(key)
+                    send_msg(s, msg)
+                    send_fds(s, {"fds": len(fds)}, fds)
+                    sent.append(key)
+                except OSError as e:
+                    _channels.drop(key)   # half a request may be on the wire: this connection is of no use any more
+                    failure = failure or f"Worker {key[0]} failed to map shared slots: {e}"
+                    break
+            for key in sent:   # every peer that got the request is heard out (see request_all)
+                try:
+                    reply = recv_msg(_channels._socks[key])
+                except Exception as e:
+                    _channels.drop(key)
+                    failure = failure or f"Worker {key[0]} failed to map shared slots: {e}"
+                    continue
                 if reply.get("status") != "success":
-                    raise RuntimeError(f"Worker {key[0]} failed to map shared slots: {reply}")
+                    failure = failure or f"Worker {key[0]} failed to map shared slots: {reply}"
+            if failure:
+                raise RuntimeError(failure)
     finally:
         for fd in fds:
             os.close(fd)
 
 
 # ------------------------------------------------------------------ collective transport
-CMD_MAP, CMD_UNMAP = 1, 2
+CMD_MAP, CMD_UNMAP, CMD_CREATED, CMD_STOP = 1, 2, 3, 4
 
 
 class CollectiveFanout:
@@ -346,22 +458,42 @@ class CollectiveFanout:
         if int(self._status.item()) != 1:
             raise RuntimeError("a tensor-parallel rank failed to (un)map KV pages")
 
-    def run(self, cmd: int, offsets: Sequence[int] = (), group_id: int = 0) -> List[int]:
-        """Broadcast (cmd, group_id, offsets) from `src`, apply locally, agree on success."""
-        cmd, group_id, offs = self._exchange(cmd, offsets, group_id)
-        ok = True
+    def _apply(self, cmd: int, offs: List[int], group_id: int) -> bool:
         try:
             if cmd == CMD_MAP:
-                ok = bool(map_to_kv_tensors(offs, group_id=group_id))
-            elif cmd == CMD_UNMAP:
-                ok = bool(unmap_from_kv_tensors(offs, group_id=group_id))
-            else:
-                ok = False
+                return bool(map_to_kv_tensors(offs, group_id=group_id))
+            if cmd == CMD_UNMAP:
+                return bool(unmap_from_kv_tensors(offs, group_id=group_id))
+            if cmd == CMD_CREATED:
+                return bool(kv_tensors_created(group_id=group_id))
+            return cmd == CMD_STOP
         except Exception as e:
             print(f"rank {self.rank}: collective (un)map failed: {e}")
-            ok = False
-        self._finish(ok)
-        return offs
+            return False
+
+    def run(self, cmd: int, offsets: Sequence[int] = (), group_id: int = 0, raise_on_failure: bool = True):
+        """Broadcast (cmd, group_id, offsets) from `src`, apply locally, agree on success. Returns the offsets (or, with
+        raise_on_failure=False, whether every rank succeeded)."""
+        cmd, group_id, offs = self._exchange(cmd, offsets, group_id)
+        ok = self._apply(cmd, offs, group_id)
+        if raise_on_failure:
+            self._finish(ok)
+            return offs
+        try:
+            self._finish(ok)
+            return True
+        except RuntimeError:
+            return False
+
+    def serve_one(self) -> bool:
+        """A non-src rank's share of one command, whatever src sends; False once src says stop."""
+        cmd, group_id, offs = self._exchange(0, (), 0)
+        ok = self._apply(cmd, offs, group_id)
+        try:
+            self._finish(ok)
+        except RuntimeError:
+            pass   # src reports the failure to the scheduler
+        return cmd != CMD_STOP
 
     def map_to_kv_tensors(self, offsets: Sequence[int] = (), group_id: int = 0) -> List[int]:
         return self.run(CMD_MAP, offsets, group_id)

@@ -25,6 +25,7 @@ using namespace kvc;
 struct FakeDriver {
   std::map<phys_handle_t, unsigned> live; // extent -> pages
   uint64_t next = 0x1000;
+  uint64_t high_bits = 0; // single-page pools: handles like ROCr's, with bits above 48 set
   size_t creates = 0, releases = 0, before_release_calls = 0, fail_after = (size_t)-1;
   bool pressure = false;
   ExtentPool *pool = nullptr;
@@ -39,7 +40,7 @@ struct FakeDriver {
                 pages, f.free_pieces, f.idle_pages);
       }
       ++creates;
-      const phys_handle_t h = next;
+      const phys_handle_t h = next | high_bits;
       next += 0x10;
       live[h] = (unsigned)pages;
       return h;
@@ -331,6 +332,19 @@ int main() {
   };
   const double tides_governed = tides(0.05, "tides_governed"), tides_ungoverned = tides(1e9, "tides_ungoverned");
   REQUIRE(tides_governed < 0.75 * tides_ungoverned, "the governor learns from the first tide (%.2f vs %.2f)", tides_governed, tides_ungoverned);
+  // single-page pools never look inside a handle: ROCr's use bits above 48
+  {
+    Harness h(1, 8, 0.05);
+    h.drv.high_bits = 0x00ab000000000000ull;
+    std::vector<int64_t> ids{1, 2, 3, 7};
+    h.map(ids);
+    for (auto &kv : h.slot) REQUIRE(kv.second.h == chunk_of(kv.second.h) && (kv.second.h >> 48) == 0xab, "handle passed through untouched");
+    h.unmap(ids);
+    REQUIRE(h.pool.footprint().idle_pages == 4 && h.pool.footprint().bad_releases == 0, "released and recycled");
+    h.map(ids);
+    REQUIRE(h.ctr.reused == 4, "reused");
+    h.unmap(ids);
+  }
   const double p90_single = churn(1, 0.05, 0, true, true, "single_pages");
   REQUIRE(p90_single == 1.0, "single pages cannot fragment");
   js += "}";

@@ -171,3 +171,62 @@ def test_collective_fanout_two_ranks_gloo():
         assert offs == [PAGE, 3 * PAGE, 5 * PAGE], results
         assert mapped == 3 * 2 * 2 and unmapped == 1 * 2 * 2
         assert failed is True
+
+
+# ------------------------------------------------------------------ persistent channels must not lose request/reply sync
+def test_a_failing_rank_does_not_leave_stale_replies_behind(cpu_pool):
+    """The connections to the workers are persistent (the reference opens one per message). If rank 0 answers "error"
+    and the caller raised before reading rank 1's reply, that reply would be taken for the answer to the NEXT request -
+    the scheduler would believe pages mapped that are not. Every rank that was written to is read before anything is
+    raised (tp_ipc_util.py request_all)."""
+    ops, capi = cpu_pool
+    from kvcached_amd import tp_ipc_util as tp
+    # rank 0: a worker that refuses every map and serves everything else; rank 1: the real listener
+    path0 = tp.get_worker_socket_path(0)
+    os.makedirs(os.path.dirname(path0), exist_ok=True)
+    if os.path.exists(path0):
+        os.remove(path0)
+    srv0 = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv0.bind(path0)
+    srv0.listen()
+    seen0 = []
+
+    def fake_rank0():
+        while True:
+            try:
+                conn, _ = srv0.accept()
+            except OSError:
+                return
+            with conn:
+                while True:
+                    try:
+                        msg = tp.recv_msg(conn)
+                    except (ConnectionError, OSError):
+                        break
+                    seen0.append(msg["cmd"])
+                    if msg["cmd"] == "map_to_kv_tensors":
+                        tp.send_msg(conn, {"status": "error", "message": "out of memory on this rank"})
+                    else:
+                        tp.send_msg(conn, {"status": "success", "created": True})
+
+    threading.Thread(target=fake_rank0, daemon=True).start()
+    srv1 = tp.start_worker_listener_thread(1)
+    try:
+        with pytest.raises(RuntimeError, match="Worker 0 failed to map"):
+            tp.broadcast_map_to_kv_tensors(2, [0])
+        assert capi.get_stats()["pages_mapped"] == 4            # rank 1 did map (2 layers x K/V): its reply was waiting
+        # the next exchange is answered by its own replies: rank 1's "created" flag, not its stale map reply
+        assert tp.broadcast_kv_tensors_created(2) is True
+        tp.broadcast_unmap_from_kv_tensors(2, [0])
+        assert capi.get_stats()["pages_unmapped"] == 4
+        assert seen0 == ["map_to_kv_tensors", "kv_tensors_created", "unmap_from_kv_tensors"]
+        # a rank whose connection breaks mid-exchange is dropped and reconnected, the others are still heard out
+        srv0.close()
+        with pytest.raises(RuntimeError, match="Worker 0 failed"):
+            for _ in range(3):                                   # the kernel may accept one more write on the dead socket
+                tp.broadcast_map_to_kv_tensors(2, [2 * PAGE])
+        assert tp._channels.request_all(2, 0, {"cmd": "kv_tensors_created", "group_id": 0}, "check", ranks=(1,))[0]["created"] is True
+    finally:
+        tp._channels.close()
+        srv0.close()
+        srv1.close()
