@@ -214,13 +214,33 @@ public:
     const int r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, (uint32_t)dmabuf, &res) : -ENODEV;
     ::close(dmabuf);
     if (r != 0 || !res.bo) return false;
-    bo_[h] = Entry{res.bo, false};
+    bo_[h] = Entry{res.bo, false, 1};
     return true;
   }
   void *find(phys_handle_t h) {
     std::lock_guard<std::mutex> g(mu_);
     auto it = bo_.find(h);
     return it == bo_.end() ? nullptr : it->second.bo;
+  }
+  // The buffer object behind a handle as the allocator stores it, and which page of it: a handle known as it stands
+  // (page 0 of its buffer: ROCr handles adopted, our own one-page buffers, imports), or a piece id (extent_pool.hpp) of
+  // one of OUR multi-page buffers - accepted only if that buffer exists, was made by create() and has exactly the size
+  // the id claims. Anything else is not a direct buffer (the caller takes ROCr's / HIP's path with the handle as it is):
+  // handles of other origins use their high bits freely and are never masked.
+  void *resolve(phys_handle_t h, unsigned *piece, unsigned *pages = nullptr) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = bo_.find(h);
+    if (it != bo_.end()) {
+      *piece = 0;
+      if (pages) *pages = 1;
+      return it->second.bo;
+    }
+    if (!is_piece(h)) return nullptr;
+    it = bo_.find(chunk_of(h));
+    if (it == bo_.end() || !it->second.kfd || it->second.pages != pages_of(h) || piece_of(h) >= it->second.pages) return nullptr;
+    *piece = piece_of(h);
+    if (pages) *pages = it->second.pages;
+    return it->second.bo;
   }
   // Drops DRM's reference; a buffer of our own making (create()) is given back to KFD as well. Returns whether the
   // handle was ours alone (nothing left for ROCr to release).
@@ -283,7 +303,7 @@ public:
     std::atomic<int64_t> alloc_ns{0}, export_ns{0}, import_ns{0}, count{0}, free_ns{0}, frees{0};
   };
   CreateTimes &create_times() { return create_times_; }
-  phys_handle_t create(size_t size) {
+  phys_handle_t create(size_t size, unsigned pages = 1) {
     KfdAlloc a{};
     a.size = size;
     a.gpu_id = gpu_id_;
@@ -302,7 +322,7 @@ public:
       std::lock_guard<std::mutex> g(mu_);
       r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, e.dmabuf_fd, &res) : -ENODEV;
       ::close((int)e.dmabuf_fd);
-      if (r == 0 && res.bo) bo_[a.handle] = Entry{res.bo, true};
+      if (r == 0 && res.bo) bo_[a.handle] = Entry{res.bo, true, (uint16_t)pages};
     }
     create_times_.alloc_ns += t1 - t0;
     create_times_.export_ns += t2 - t1;
@@ -333,7 +353,7 @@ public:
       std::lock_guard<std::mutex> g(mu_);
       r = dev_ ? api_.bo_import(dev_, kHandleTypeDmaBufFd, e.dmabuf_fd, &res) : -ENODEV;
       ::close((int)e.dmabuf_fd);
-      if (r == 0 && res.bo) bo_[m.handle] = Entry{res.bo, true};
+      if (r == 0 && res.bo) bo_[m.handle] = Entry{res.bo, true, 1};
     }
     if (r != 0 || !res.bo) {
       KfdFree f{m.handle};
@@ -405,6 +425,7 @@ private:
   struct Entry {
     void *bo;  // amdgpu_bo_handle
     bool kfd;  // allocated by create(): the key is KFD's handle, not ROCr's
+    uint16_t pages = 1; // ... and how many pages it has (an extent: extent_pool.hpp)
   };
   // include/uapi/linux/kfd_ioctl.h, restated (the image's header predates EXPORT_DMABUF)
   struct KfdAlloc { // kfd_ioctl_alloc_memory_of_gpu_args

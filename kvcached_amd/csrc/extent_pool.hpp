@@ -121,7 +121,7 @@ public:
     lk.unlock();
     const phys_handle_t h = drv_.create(n); // may throw: nothing of ours has changed yet
     lk.lock();
-    if (n > 1 && (h >> kPagesShift) != 0) { // cannot be told apart from a piece id: never happens with KFD handles
+    if (kmax_cfg_ > 1 && (h >> kPagesShift) != 0) { // cannot be told apart from a piece id: never happens with KFD handles
       lk.unlock();
       (void)drv_.release(h);
       throw std::runtime_error("extent pool: a multi-page buffer handle does not fit 48 bits");
@@ -147,10 +147,10 @@ public:
     {
       std::lock_guard<std::mutex> g(mu_);
       for (size_t i = 0; i < n; ++i) {
-        const phys_handle_t h = chunk_of(ps[i].h);
+        const phys_handle_t h = key_of(ps[i].h);
         auto it = tracked_.find(h);
-        const uint64_t bit = 1ull << piece_of(ps[i].h);
-        if (it == tracked_.end() || (it->second.free_mask & bit) || piece_of(ps[i].h) >= it->second.n) {
+        const uint64_t bit = 1ull << idx_of(ps[i].h);
+        if (it == tracked_.end() || (it->second.free_mask & bit) || idx_of(ps[i].h) >= it->second.n) {
           ++bad_releases_; // a piece of an unknown extent, or one that is not out: never corrupt the masks
           continue;
         }
@@ -290,7 +290,7 @@ public:
   // how many pieces of this extent are handed out (0: unknown or whole)
   unsigned pieces_out(phys_handle_t extent) {
     std::lock_guard<std::mutex> g(mu_);
-    auto it = tracked_.find(chunk_of(extent));
+    auto it = tracked_.find(key_of(extent));
     return it == tracked_.end() ? 0 : (unsigned)__builtin_popcountll(full_mask(it->second.n) & ~it->second.free_mask);
   }
 
@@ -312,6 +312,10 @@ private:
     uint64_t seq;
     unsigned n;
   };
+  // Handles are only ever taken apart in a pool that makes multi-page extents (its buffers are KFD's, below 2^48);
+  // a single-page pool passes whatever its driver returns through untouched (ROCr's handles use the high bits).
+  phys_handle_t key_of(phys_handle_t h) const { return kmax_cfg_ > 1 ? chunk_of(h) : h; }
+  unsigned idx_of(phys_handle_t h) const { return kmax_cfg_ > 1 ? piece_of(h) : 0; }
   static uint64_t full_mask(unsigned n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); }
   // lowest start of `want` consecutive set bits, or -1
   static int find_run(uint64_t mask, unsigned want) {

@@ -224,10 +224,12 @@ inline bool vmm_try_address_free(void *va, size_t size) {
 }
 // `direct`: with the drm backend, also import the handle into DRM so that vmm_map/vmm_unmap take the one-ioctl path
 // (false for handles that are mapped many times over - the zero aliases - which stay with ROCr).
-inline phys_handle_t vmm_create(int dev, size_t size, bool exportable, bool direct = true) {
+// `pages`: how many pages of the pool the buffer holds (an extent; only the drm backend with KFD allocation makes > 1)
+inline phys_handle_t vmm_create(int dev, size_t size, bool exportable, bool direct = true, unsigned pages = 1) {
   if (vmm_uses_rocr()) {
     if (direct && vmm_backend() == kVmmDrm && DrmVm::instance().hip_dev() == dev && DrmVm::instance().kfd_ready())
-      return DrmVm::instance().create(size); // flat 5 us instead of O(live handles)
+      return DrmVm::instance().create(size, pages); // flat 5 us instead of O(live handles)
+    if (pages > 1) throw GpuError("multi-page extents need buffers straight from KFD");
     hsa_amd_vmem_alloc_handle_t h{};
     HSA_CHECK(hsa_amd_vmem_handle_create(hsa_device(dev).pool, size, MEMORY_TYPE_PINNED, 0, &h));
     if (direct && vmm_backend() == kVmmDrm && DrmVm::instance().hip_dev() == dev && !DrmVm::instance().adopt(h.handle)) {
@@ -246,18 +248,31 @@ inline bool vmm_try_release(phys_handle_t h) {
   if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }
-inline void *vmm_direct_bo(phys_handle_t h) { return vmm_backend() == kVmmDrm ? DrmVm::instance().find(chunk_of(h)) : nullptr; }
-// `count` pieces of one chunk with consecutive indices, starting with `h_first`, behind `count` adjacent slots: ONE ioctl.
+// The DRM buffer object behind a handle and the page of it the handle names (DrmVm::resolve); nullptr: not a direct buffer.
+inline void *vmm_direct_bo(phys_handle_t h, unsigned *piece = nullptr, unsigned *pages = nullptr) {
+  unsigned p = 0;
+  void *bo = vmm_backend() == kVmmDrm ? DrmVm::instance().resolve(h, &p, pages) : nullptr;
+  if (piece) *piece = p;
+  return bo;
+}
+// pages of the buffer a handle is a piece of (1: a whole buffer, or not ours to look into)
+inline unsigned vmm_extent_pages(phys_handle_t h) {
+  unsigned piece = 0, pages = 1;
+  return vmm_direct_bo(h, &piece, &pages) ? pages : 1;
+}
+// `count` pieces of one extent with consecutive indices, starting with `h_first`, behind `count` adjacent slots: ONE ioctl.
 inline void vmm_map_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first) {
-  void *bo = vmm_direct_bo(h_first);
+  unsigned piece = 0;
+  void *bo = vmm_direct_bo(h_first, &piece);
   if (!bo) throw GpuError("vmm_map_pieces: not a direct DRM buffer");
-  const int r = DrmVm::instance().map(bo, va, count * piece_bytes, static_cast<uint64_t>(piece_of(h_first)) * piece_bytes);
+  const int r = DrmVm::instance().map(bo, va, count * piece_bytes, static_cast<uint64_t>(piece) * piece_bytes);
   if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
 }
 // Returns whether the mapping still needs vmm_set_access (a DRM mapping is made readable+writable in the same ioctl).
 inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
-  if (void *bo = vmm_direct_bo(h)) {
-    const int r = DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece_of(h)) * size);
+  unsigned piece = 0;
+  if (void *bo = vmm_direct_bo(h, &piece)) {
+    const int r = DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece) * size);
     if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
     return false;
   }
@@ -268,7 +283,8 @@ inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
   return true;
 }
 inline bool vmm_try_map(void *va, size_t size, phys_handle_t h) {
-  if (void *bo = vmm_direct_bo(h)) return DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece_of(h)) * size) == 0;
+  unsigned piece = 0;
+  if (void *bo = vmm_direct_bo(h, &piece)) return DrmVm::instance().map(bo, va, size, static_cast<uint64_t>(piece) * size) == 0;
   if (vmm_uses_rocr()) return hsa_amd_vmem_map(va, size, 0, as_hsa(h), 0) == HSA_STATUS_SUCCESS;
   return hipMemMap(va, size, 0, as_hip(h), 0) == hipSuccess;
 }

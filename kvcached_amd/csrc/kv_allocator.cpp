@@ -153,7 +153,7 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
     d.create = [dev, page_bytes, exportable](size_t pages) -> phys_handle_t {
       if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
         hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-      return vmm_create(dev, pages * page_bytes, exportable);
+      return vmm_create(dev, pages * page_bytes, exportable, true, (unsigned)pages);
     };
     d.release = [](phys_handle_t h) {
       const bool ok = vmm_try_release(h);
@@ -1400,7 +1400,7 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
     vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
-    if (pages_of(r.handle[s.index]) > 1) // one page out of a larger mapping: see unmap_collect
+    if (vmm_extent_pages(r.handle[s.index]) > 1) // one page out of a larger mapping: see unmap_collect
       if (void *bo = vmm_direct_bo(r.handle[s.index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
@@ -1638,7 +1638,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
       (void)vmm_try_unmap(va, ps, r.handle[it->index]);
-      if (pages_of(r.handle[it->index]) > 1)
+      if (vmm_extent_pages(r.handle[it->index]) > 1)
         if (void *bo = vmm_direct_bo(r.handle[it->index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
       if (r.mapped[it->index] == 1)
         pool->release(Phys{r.handle[it->index], r.seq[it->index]});
@@ -1752,7 +1752,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       u.imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
     ++u.n;
-    if (own && pages_of(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
+    if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();

@@ -370,6 +370,57 @@ def gen_prefix_cache():
     dump("prefix_cache.json", {"meta": META, "cache_keys": keys, "cases": cases})
 
 
+# ------------------------------------------------------------------ 8. get_avail_physical_pages on fed readings
+_AVAIL_CHILD = r"""
+import importlib.machinery, importlib.util, json, os, sys
+import torch
+so, rows_in = sys.argv[1], json.loads(sys.argv[2])
+loader = importlib.machinery.ExtensionFileLoader("vmm_ops", so)
+spec = importlib.util.spec_from_loader("vmm_ops", loader)
+ref = importlib.util.module_from_spec(spec); loader.exec_module(ref)
+PAGE = 2 << 20
+ref.init_kvcached("cpu", PAGE, False)
+out, pas = [], {}
+for free, total, L, kv in rows_in:
+    if (L, kv) not in pas:
+        pas[(L, kv)] = ref.PageAllocator(L, 64 * PAGE, PAGE, 1, 0, False, False, False, kv, 0, os.environ["KVCACHED_IPC_NAME"] + f"_av{L}_{kv}")
+    os.environ["KVC_FEED_FREE"], os.environ["KVC_FEED_TOTAL"] = str(free), str(total)
+    out.append([free, total, L, kv, int(pas[(L, kv)].get_avail_physical_pages())])
+pas.clear()
+ref.shutdown_kvcached()
+print(json.dumps(out))
+"""
+
+
+def gen_avail_physical():
+    """The reference's OWN arithmetic (csrc/page_allocator.cpp:442-455) on (free, total) readings that are inputs: the
+    real reference .so in a child process with oracle/_ref/libmemfeed.so preloaded (it answers hipMemGetInfo - and only
+    that - with the pair in the environment). Includes readings below the headroom, where the reference's unsigned
+    subtraction wraps."""
+    import subprocess
+    feed = os.path.join(os.path.dirname(REF_SO), "libmemfeed.so")
+    GiB = 1 << 30
+    total = 288 * GiB
+    frees = [0, 1, PAGE, 5 * GiB, int(total * 0.05) - 1, int(total * 0.05), int(total * 0.05) + PAGE - 1, int(total * 0.05) + PAGE,
+             int(total * 0.05) + 64 * PAGE, 20 * GiB, 100 * GiB + 12345, 287 * GiB, total]
+    rows_in = [[f, total, L, kv] for f in frees for (L, kv) in ((1, 1), (2, 2), (32, 2), (61, 1), (80, 2))]
+    rows_in += [[f, 80 * GiB, 32, 2] for f in (0, 3 * GiB, 4 * GiB, 4 * GiB + 64 * PAGE * 64, 79 * GiB)]
+    cases = []
+    for util in (None, "0.5", "1.0"):
+        env = dict(os.environ, LD_PRELOAD=feed)
+        env.pop("KVCACHED_GPU_UTILIZATION", None)
+        if util is not None:
+            env["KVCACHED_GPU_UTILIZATION"] = util
+        out = subprocess.run([sys.executable, "-c", _AVAIL_CHILD, REF_SO, json.dumps(rows_in)], env=env, capture_output=True,
+                             text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("[[")]
+        assert out.returncode == 0 and line, out.stderr[-2000:]
+        cases.append({"gpu_utilization": 0.95 if util is None else float(util), "rows": json.loads(line[-1])})
+    dump("avail_physical_pages.json", {"meta": META, "page_size": PAGE, "columns": ["free_bytes", "total_bytes", "num_layers",
+                                                                                  "num_kv_buffers", "avail_pages_per_layer"],
+                                      "cases": cases})
+
+
 if __name__ == "__main__":
     t0 = time.time()
     print("reference module:", ref_ops.__file__ if hasattr(ref_ops, "__file__") else REF_SO)
@@ -380,4 +431,5 @@ if __name__ == "__main__":
     gen_manager()
     gen_layouts()
     gen_prefix_cache()
+    gen_avail_physical()
     print(f"done in {time.time() - t0:.1f}s")

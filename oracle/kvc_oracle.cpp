@@ -568,6 +568,17 @@ void okvc_pa_trim(void *h) { ((OPageAllocator *)h)->trim(); }
 void okvc_pa_reset_free_page_order(void *h) { ((OPageAllocator *)h)->reset_free_page_order(); }
 int64_t okvc_pa_prealloc_step(void *h) { return ((OPageAllocator *)h)->prealloc_step(); }
 void okvc_pa_set_prealloc_needed(void *h, int v) { ((OPageAllocator *)h)->prealloc_needed = v != 0; }
+// The reference's get_avail_physical_pages arithmetic (csrc/page_allocator.cpp:442-455) on a given hipMemGetInfo reading,
+// restated with its types: size_t subtraction (WRAPS when free < headroom - std::max(x - y, 0) on unsigned values is a no-op),
+// then int64 divisions. Pinned by tests/golden/avail_physical_pages.json (the real reference on fed readings).
+int64_t okvc_ref_avail_physical_pages(uint64_t free_b, uint64_t total_b, double gpu_utilization, int64_t page_size,
+                                      int64_t num_layers, int64_t num_kv_buffers) {
+  size_t avail = (size_t)free_b;
+  const size_t headroom = (size_t)((double)total_b * (1.0 - gpu_utilization));
+  avail = std::max(avail - headroom, static_cast<size_t>(0));
+  const int64_t avail_phy_pages = (int64_t)(avail / (size_t)page_size);
+  return avail_phy_pages / num_layers / num_kv_buffers;
+}
 void okvc_pa_set_avail_phys_pages(void *h, int64_t v) { ((OPageAllocator *)h)->avail_phys_pages = v; }
 void okvc_pa_set_shm_total(void *h, int64_t v) { ((OPageAllocator *)h)->shm_total = v; }
 void okvc_pa_watcher_tick(void *h) { ((OPageAllocator *)h)->watcher_tick(); }

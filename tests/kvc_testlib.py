@@ -140,6 +140,7 @@ def load_oracle() -> ctypes.CDLL:
         "okvc_last_error": (ctypes.c_char_p, []),
         "okvc_get_block_range": (None, [i64, i64, i64, _I64P, _I64P]),
         "okvc_get_num_blocks": (i64, [i64, i64]),
+        "okvc_ref_avail_physical_pages": (i64, [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, i64, i64, i64]),
         "okvc_page_new": (vp, [i64, i64]), "okvc_page_delete": (None, [vp]),
         "okvc_page_init": (None, [vp, i64]), "okvc_page_alloc": (i64, [vp, i64, _I64P]),
         "okvc_page_free": (None, [vp, i64]), "okvc_page_free_batch": (None, [vp, _I64P, i64]),

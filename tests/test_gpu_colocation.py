@@ -106,7 +106,9 @@ def test_two_engines_share_one_gpu():
         got = _ask(a, "alloc", 6 * BLOCKS_PER_GIB)
         assert got == 6 * BLOCKS_PER_GIB, (got, a0, b0)
         b1 = _ask(b, "avail")
-        assert b1 <= b0 - 5 * BLOCKS_PER_GIB, (b0, b1)
+        # (up to RESERVE_MB of A's growth comes out of the reserve A was already holding - B had seen that as used - and
+        # A's housekeeping refills it a tick later)
+        assert b1 <= b0 - (5 * BLOCKS_PER_GIB - RESERVE_MB * BLOCKS_PER_GIB // 1024), (b0, b1)
         got = _ask(b, "alloc", 4 * BLOCKS_PER_GIB)
         assert got is None, (got, b0, b1)
 
@@ -122,9 +124,10 @@ def test_two_engines_share_one_gpu():
         b2, took = _wait_for(lambda: _ask(b, "avail"), lambda v: v >= b0 - BLOCKS_PER_GIB, timeout=20)
         assert took is not None, f"B still sees {b2} blocks (started with {b0}) 10 s after A freed 6 GiB"
         # ... because the handles really went back to the driver (all but the reserved pages, a few ticks later)
-        # (created - released = what the engine still holds: the reserved page ids, still mapped, and the physical reserve)
-        sa, took_all = _wait_for(lambda: _ask(a, "stats"),
-                                 lambda st: st["created"] - st["released"] <= 200 + RESERVE_MB * (1 << 20) // PAGE, timeout=20)
+        # (created - released = what the engine still holds: the physical reserve, the reserved page ids - still mapped,
+        # 8 slots each - and, per region, at most one extent that such a mapped page keeps from going back whole)
+        keeps = RESERVE_MB * (1 << 20) // PAGE + 10 * LAYERS * 2 + LAYERS * 2 * 32
+        sa, took_all = _wait_for(lambda: _ask(a, "stats"), lambda st: st["created"] - st["released"] <= keeps, timeout=20)
         assert took_all is not None, sa
         got = _ask(b, "alloc", 4 * BLOCKS_PER_GIB)
         assert got == 4 * BLOCKS_PER_GIB, (got, b0, b2)
