@@ -61,13 +61,19 @@ struct VmmCounters { // in pages
 };
 
 // A physical page plus the creation order of its extent.
+// scrub_ticket: 0 = the page may hold old data and must be zeroed by whoever maps it; otherwise it has been zeroed (or is
+// being zeroed) by scrub number `scrub_ticket` on the owner's stream - wait for that one, write nothing.
 struct Phys {
   phys_handle_t h{};
   uint64_t seq = 0;
+  uint64_t scrub_ticket = 0;
 };
 
 struct ExtentDriver {
-  std::function<phys_handle_t(size_t pages)> create; // one buffer of `pages` pages; throws on failure
+  // one buffer of `pages` pages; throws on failure. *tag (optional, 0 = none): an address at which the whole buffer stays
+  // mapped for the pool's owner - the alias its pages are zeroed through after they come back (see scrub_addresses)
+  std::function<phys_handle_t(size_t pages, uint64_t *tag)> create;
+  std::function<void(phys_handle_t extent, uint64_t tag, size_t pages)> prepare_release; // per victim, before before_release (drop the alias)
   std::function<bool(phys_handle_t extent)> release; // back to the driver
   std::function<void()> before_release;              // once before a batch of releases (a TLB invalidation that was owed)
   std::function<bool()> under_pressure;              // the device is short of free memory: keep nothing idle
@@ -119,10 +125,12 @@ public:
     if (!may_create) return 0;
     const unsigned n = (unsigned)std::min<size_t>(want, kmax_cur_);
     lk.unlock();
-    const phys_handle_t h = drv_.create(n); // may throw: nothing of ours has changed yet
+    uint64_t tag = 0;
+    const phys_handle_t h = drv_.create(n, &tag); // may throw: nothing of ours has changed yet
     lk.lock();
     if (kmax_cfg_ > 1 && (h >> kPagesShift) != 0) { // cannot be told apart from a piece id: never happens with KFD handles
       lk.unlock();
+      if (drv_.prepare_release) drv_.prepare_release(h, tag, n);
       (void)drv_.release(h);
       throw std::runtime_error("extent pool: a multi-page buffer handle does not fit 48 bits");
     }
@@ -132,6 +140,9 @@ public:
     e.free_mask = full_mask(n);
     e.used_mask = 0;
     e.bucket = 0;
+    e.tag = tag;
+    e.clean_mask = 0; // what the driver hands out is zero today, but that is not a documented guarantee
+    e.ticket = 0;
     free_pieces_ += n;
     held_pages_ += n;
     ctr_->created += n;
@@ -139,8 +150,24 @@ public:
     return take_pieces_locked(h, e, 0, n, out, recycled);
   }
 
+  // Where the pages `ps` can be zeroed after their slots were unmapped: out[i] = the address of piece i inside its
+  // extent's alias mapping, or 0 if the extent has none. The owner launches its fill on those addresses FIRST and then
+  // gives the pages back with release_batch(ps, n, ticket) - a page must never be on offer before its scrub is queued.
+  size_t scrub_addresses(const Phys *ps, size_t n, uint64_t *out) {
+    std::lock_guard<std::mutex> g(mu_);
+    size_t have = 0;
+    for (size_t i = 0; i < n; ++i) {
+      auto it = tracked_.find(key_of(ps[i].h));
+      out[i] = (it != tracked_.end() && it->second.tag) ? it->second.tag + (uint64_t)idx_of(ps[i].h) * page_bytes_ : 0;
+      have += out[i] != 0;
+    }
+    return have;
+  }
+
   void release(Phys p) { release_batch(&p, 1); }
-  void release_batch(const Phys *ps, size_t n) {
+  // `scrub_ticket` != 0: the pages that have an alias address were queued for zeroing as scrub number `scrub_ticket`
+  // (scrub_addresses above); whoever gets them next waits for that scrub instead of zeroing them again.
+  void release_batch(const Phys *ps, size_t n, uint64_t scrub_ticket = 0) {
     if (n == 0) return;
     std::vector<Victim> victims;
     const bool pressure = drv_.under_pressure && drv_.under_pressure();
@@ -156,12 +183,18 @@ public:
         }
         Extent &e = it->second;
         e.free_mask |= bit;
+        if (scrub_ticket && e.tag) {
+          e.clean_mask |= bit;
+          e.ticket = std::max(e.ticket, scrub_ticket);
+        } else {
+          e.clean_mask &= ~bit;
+        }
         ++free_pieces_;
         --out_pieces_;
         if (e.free_mask == full_mask(e.n)) { // the extent is whole again: idle, ours to reuse or to give back
           unbucket_locked(h, e);
           free_pieces_ -= e.n;
-          idle_insert_locked(h, e.seq, e.n, true);
+          idle_insert_locked(h, IdleInfo{e.seq, e.n, true, e.tag, e.clean_mask, e.ticket});
           tracked_.erase(it);
         } else {
           rebucket_locked(h, e);
@@ -253,15 +286,16 @@ public:
       }
       if (drv_.under_pressure && drv_.under_pressure()) break;
       phys_handle_t h;
+      uint64_t tag = 0;
       try {
-        h = drv_.create(n);
+        h = drv_.create(n, &tag);
       } catch (...) {
         break; // no memory: the reserve is a convenience
       }
       std::lock_guard<std::mutex> g(mu_);
       held_pages_ += n;
       ctr_->created += n;
-      idle_insert_locked(h, ++next_seq_, n, false);
+      idle_insert_locked(h, IdleInfo{++next_seq_, (uint8_t)n, false, tag, 0, 0});
       made += n;
     }
     return made;
@@ -298,19 +332,24 @@ private:
   struct Extent {
     uint64_t seq = 0;
     uint64_t free_mask = 0;
-    uint64_t used_mask = 0; // pieces that have been handed out before (their memory may hold old data)
+    uint64_t used_mask = 0;  // pieces that have been handed out before (their memory may hold old data)
+    uint64_t clean_mask = 0; // free pieces that were queued for zeroing when they came back ...
+    uint64_t ticket = 0;     // ... by scrubs up to this number
+    uint64_t tag = 0;        // the driver's alias address of the buffer (0: none)
     uint8_t n = 1;
-    uint8_t bucket = 0;     // longest free run (0: none free, not in by_run_)
+    uint8_t bucket = 0;      // longest free run (0: none free, not in by_run_)
   };
   struct IdleInfo {
     uint64_t seq;
     uint8_t n;
     bool used;
+    uint64_t tag, clean_mask, ticket;
   };
   struct Victim {
     phys_handle_t h;
     uint64_t seq;
     unsigned n;
+    uint64_t tag;
   };
   // Handles are only ever taken apart in a pool that makes multi-page extents (its buffers are KFD's, below 2^48);
   // a single-page pool passes whatever its driver returns through untouched (ROCr's handles use the high bits).
@@ -350,7 +389,8 @@ private:
       e.free_mask &= ~bit;
       old += (e.used_mask & bit) != 0;
       e.used_mask |= bit;
-      out[i] = Phys{piece_id(h, first + i, e.n), e.seq};
+      out[i] = Phys{piece_id(h, first + i, e.n), e.seq, (e.clean_mask & bit) ? std::max<uint64_t>(e.ticket, 1) : 0};
+      e.clean_mask &= ~bit; // in somebody's hands now
     }
     free_pieces_ -= n;
     out_pieces_ += n;
@@ -384,15 +424,18 @@ private:
     e.free_mask = full_mask(size);
     e.used_mask = info.used ? full_mask(size) : 0;
     e.bucket = 0;
+    e.tag = info.tag;
+    e.clean_mask = info.clean_mask;
+    e.ticket = info.ticket;
     free_pieces_ += size;
     take_pieces_locked(h, e, 0, take, out, recycled);
     return true;
   }
-  void idle_insert_locked(phys_handle_t h, uint64_t seq, unsigned n, bool used) {
-    idle_n_[n].insert({seq, h});
-    idle_all_.insert({seq, h});
-    idle_info_[h] = IdleInfo{seq, (uint8_t)n, used};
-    idle_pages_ += n;
+  void idle_insert_locked(phys_handle_t h, const IdleInfo &info) {
+    idle_n_[info.n].insert({info.seq, h});
+    idle_all_.insert({info.seq, h});
+    idle_info_[h] = info;
+    idle_pages_ += info.n;
   }
   bool pop_oldest_idle_locked(std::vector<Victim> *victims) {
     if (idle_all_.empty()) return false;
@@ -402,7 +445,7 @@ private:
     idle_info_.erase(key.second);
     idle_n_[info.n].erase(key);
     idle_pages_ -= info.n;
-    victims->push_back(Victim{key.second, key.first, info.n});
+    victims->push_back(Victim{key.second, key.first, info.n, info.tag});
     return true;
   }
   // Waste = free pieces inside partly used extents. Above waste_frac of the pages in use, new extents halve at once
@@ -422,7 +465,9 @@ private:
   }
   void to_driver(std::vector<Victim> &v) {
     if (v.empty()) return;
-    if (drv_.before_release) drv_.before_release();
+    if (drv_.prepare_release)
+      for (auto &p : v) drv_.prepare_release(p.h, p.tag, p.n); // aliases go first: their translations are covered by ...
+    if (drv_.before_release) drv_.before_release();            // ... the invalidation owed before memory leaves
     std::sort(v.begin(), v.end(), [](const Victim &a, const Victim &b) { return a.seq < b.seq; }); // oldest first
     size_t pages = 0;
     for (auto &p : v) {

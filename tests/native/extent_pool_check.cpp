@@ -27,12 +27,17 @@ struct FakeDriver {
   uint64_t next = 0x1000;
   uint64_t high_bits = 0; // single-page pools: handles like ROCr's, with bits above 48 set
   size_t creates = 0, releases = 0, before_release_calls = 0, fail_after = (size_t)-1;
-  bool pressure = false;
+  bool pressure = false, give_tags = false;
+  size_t prepared = 0;
   ExtentPool *pool = nullptr;
   bool check_no_waste_at_create = true;
   ExtentDriver make() {
     ExtentDriver d;
-    d.create = [this](size_t pages) -> phys_handle_t {
+    d.prepare_release = [this](phys_handle_t h, uint64_t tag, size_t pages) {
+      REQUIRE(live.count(h) && live[h] == pages && tag == (give_tags ? 0x7000000000ull + (h & 0xffffffffull) * 0x100000 : 0), "prepare_release of the right extent");
+      ++prepared;
+    };
+    d.create = [this](size_t pages, uint64_t *tag) -> phys_handle_t {
       if (creates >= fail_after) throw std::runtime_error("out of memory [injected]");
       if (pool && check_no_waste_at_create) {
         auto f = pool->footprint();
@@ -43,6 +48,7 @@ struct FakeDriver {
       const phys_handle_t h = next | high_bits;
       next += 0x10;
       live[h] = (unsigned)pages;
+      if (tag) *tag = give_tags ? 0x7000000000ull + (h & 0xffffffffull) * 0x100000 : 0;
       return h;
     };
     d.release = [this](phys_handle_t h) {
@@ -239,6 +245,30 @@ int main() {
     h.pool.release(bogus);
     Phys first = p[0];
     (void)first;
+  }
+  // 4b. scrub tickets: pages zeroed on their way back are not zeroed again on their way out
+  {
+    Harness h(16, 1 << 20, 0.05);
+    h.drv.give_tags = true;
+    Phys p[16], q[16];
+    bool rec;
+    REQUIRE(h.pool.acquire_run(8, p, &rec, true) == 8, "eight fresh pages");
+    for (int i = 0; i < 8; ++i) REQUIRE(p[i].scrub_ticket == 0, "fresh memory is zeroed by whoever maps it");
+    uint64_t addr[16];
+    REQUIRE(h.pool.scrub_addresses(p, 8, addr) == 8, "every page has an alias address");
+    for (int i = 1; i < 8; ++i) REQUIRE(addr[i] == addr[0] + (uint64_t)i * (2u << 20), "alias addresses follow the piece index");
+    h.pool.release_batch(p, 5, 7);            // five pages back, queued as scrub 7
+    h.pool.release_batch(p + 5, 3);           // three without a scrub (e.g. zero fill switched off)
+    REQUIRE(h.pool.acquire_run(8, q, &rec, false) == 8, "the whole extent again");
+    for (int i = 0; i < 8; ++i) REQUIRE(q[i].scrub_ticket == (i < 5 ? 7u : 0u), "page %d: ticket %llu", i, (unsigned long long)q[i].scrub_ticket);
+    h.pool.release_batch(q, 8, 9);
+    REQUIRE(h.pool.acquire_run(3, q, &rec, false) == 3 && q[0].scrub_ticket == 9 && q[2].scrub_ticket == 9, "partial reuse keeps the tickets");
+    h.pool.release_batch(q, 3);               // used and returned unscrubbed: dirty again
+    REQUIRE(h.pool.acquire_run(8, q, &rec, false) == 8, "all eight");
+    for (int i = 0; i < 8; ++i) REQUIRE(q[i].scrub_ticket == (i < 3 ? 0u : 9u), "page %d after a dirty return", i);
+    h.pool.release_batch(q, 8, 11);
+    h.pool.drain(0);
+    REQUIRE(h.drv.prepared == 1 && h.drv.live.empty(), "the alias is dropped before the buffer goes back");
   }
   // 5. churn: runs mapped together, freed together most of the time (a request's pages) with stragglers
   std::mt19937_64 rng(1);

@@ -1,0 +1,190 @@
+"""The two integration-level goldens on the real device:
+
+a19  alloc_kv_cache layouts (kvcached/integration/{vllm,sglang}/interfaces.py:196-298): the reference's shapes, strides and
+     byte offsets checked on views of REAL reserved VA on cuda:0 - and a page mapped behind them is reachable through every
+     layer's view at exactly the bytes the layout says.
+f1   ElasticBlockPool (kvcached/integration/vllm/patches.py:308-614): the reference's recorded request traces replayed over a
+     GPU-backed KVCacheManager; every block is signed in device memory when it is filled and a prefix-cache HIT must find
+     the signature intact - i.e. cached blocks keep their pages (and their contents) while they sit evictable."""
+import json
+import os
+
+import pytest
+import torch
+
+import kvc_testlib as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LAYOUTS = json.load(open(os.path.join(T.GOLDEN_DIR, "alloc_kv_cache_layouts.json")))["cases"]
+PREFIX = json.load(open(os.path.join(T.GOLDEN_DIR, "prefix_cache.json")))
+
+
+class _Props:
+    def __init__(self, total):
+        self.total_memory = total
+
+
+def _desc(t, base):
+    return {"shape": list(t.shape), "stride": list(t.stride()), "dtype": str(t.dtype),
+            "offset_bytes": int(t.data_ptr() - base), "storage_offset": int(t.storage_offset())}
+
+
+@pytest.mark.parametrize("idx", range(len(LAYOUTS)))
+def test_layout_on_real_va_matches_reference(monkeypatch, idx):
+    rec = LAYOUTS[idx]
+    c = rec["case"]
+    import kvcached_amd.integration.sglang.interfaces as sg
+    import kvcached_amd.integration.vllm.interfaces as vl
+    from kvcached_amd import vmm_ops
+    mod = vl if c["engine"] == "vllm" else sg
+    # the golden was recorded for a device of c["gpu_bytes"]: the size of the reservation follows from it
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev=None: _Props(c["gpu_bytes"]))
+    monkeypatch.setattr(mod, "_kvcached_initialized", True)
+    monkeypatch.setattr(mod, "_contiguous_layout", c["contiguous"])
+    captured = {}
+    real = vmm_ops.create_kv_tensors
+
+    def spy(size, dtype_size, dev, num_layers, num_kv_buffers=2, group_id=0, unified_pool=False):
+        captured.update(size=int(size), dtype_size=int(dtype_size), num_layers=int(num_layers),
+                        num_kv_buffers=int(num_kv_buffers), unified_pool=bool(unified_pool))
+        ts = real(size, dtype_size, dev, num_layers, num_kv_buffers, group_id, unified_pool)
+        captured["bases"] = [int(t.data_ptr()) for t in ts]
+        captured["raw"] = ts
+        return ts
+
+    monkeypatch.setattr(mod, "create_kv_tensors", spy)
+    vmm_ops.init_kvcached(DEV, 2 << 20, c["contiguous"])
+    try:
+        dtype = getattr(torch, c["dtype"])
+        if c["engine"] == "vllm":
+            out = mod.alloc_kv_cache(tuple(c["shape"]), c["block_size"], dtype, DEV, c["num_layers"],
+                                     attention_type=c["attention_type"], kernel_block_size=c.get("kernel_block_size"))
+        else:
+            out = mod.alloc_kv_cache(tuple(c["shape"]), dtype, DEV, c["num_layers"], page_size=c["block_size"],
+                                     attention_type=c["attention_type"])
+        bases, raw = captured.pop("bases"), captured.pop("raw")
+        assert captured == rec["create_kv_tensors"]
+        assert all(b % (2 << 20) == 0 for b in bases)                      # real reservations, page aligned
+        extra = None
+        if c["attention_type"] == "HYBRID_LINEAR":
+            out, extra = out
+
+        def descs(tensors):
+            assert all(t.device == torch.device(DEV) for t in tensors)
+            return [_desc(t, bases[0] if c["contiguous"] else bases[i]) for i, t in enumerate(tensors)][:3]
+
+        views = []
+        if isinstance(out, tuple):
+            assert descs(out[0]) == rec["k"] and descs(out[1]) == rec["v"]
+            assert len(out[0]) == len(out[1]) == c["num_layers"]
+            views = [out[0][0], out[1][0], out[0][-1], out[1][-1]]
+        else:
+            assert descs(out) == rec["kv"] and len(out) == c["num_layers"]
+            views = [out[0], out[-1]]
+        if extra is not None:
+            got = {k: (v if not isinstance(v, list) else [list(b.shape) for b in v][:2]) for k, v in extra.items()}
+            assert got == rec["raw_info"]
+        # back page id 0 everywhere and reach it through the views: the first element of every view lies in that page
+        # (K at offset 0; V either in the same compound page or at size/2 - both are slots of page id 0)
+        assert vmm_ops.map_to_kv_tensors([0])
+        firsts = {}
+        for v in views:
+            firsts.setdefault(v.data_ptr(), v[(0,) * v.dim()])              # a 0-d view of the element the layout puts first
+        for n, f in enumerate(firsts.values()):
+            assert float(f) == 0                                            # zero-filled, and not a fault
+            f.fill_(n + 1)
+        torch.cuda.synchronize()
+        for n, f in enumerate(firsts.values()):
+            assert float(f) == n + 1                                        # distinct places, no aliasing between them
+        assert vmm_ops.unmap_from_kv_tensors([0])
+        del raw, views, out
+    finally:
+        vmm_ops.shutdown_kvcached()
+
+
+def _blk_view(tensors, block_id, block_bytes):
+    """The int64 words of block `block_id` in K and V of every layer (raw per-layer tensors: K half, V half)."""
+    words = block_bytes // 8
+    out = []
+    for t in tensors:
+        w = t.view(torch.int64)
+        half = w.numel() // 2
+        out += [w[block_id * words:(block_id + 1) * words], w[half + block_id * words:half + (block_id + 1) * words]]
+    return out
+
+
+@pytest.mark.parametrize("name", ["default_cap_1000", "cap_5", "tiny_pool_pressure"])
+def test_prefix_cache_trace_over_a_gpu_backed_manager(monkeypatch, name):
+    case = next(c for c in PREFIX["cases"] if c["config"]["name"] == name)
+    cfg = case["config"]
+    import kvcached_amd.integration.vllm.interfaces as vi
+    from kvcached_amd import capi, vmm_ops
+    from kvcached_amd.integration.vllm.block_pool import build_elastic_block_pool
+    layers, block_tokens, cell = 2, 16, 16384                               # 256 KiB blocks: 8 per 2 MiB page
+    block_bytes = block_tokens * cell
+    n = cfg["num_blocks"]
+    pages = -(-n * block_bytes // T.PAGE)
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    monkeypatch.setattr(vi, "_kvcached_initialized", True)
+    monkeypatch.setattr(vi, "_is_worker", True)
+    try:
+        raw = vmm_ops.create_kv_tensors(pages * T.PAGE * 2, 1, DEV, layers, 2, 0, False)
+        cls = build_elastic_block_pool(T.FakeBlockPool, T.FakeKVCacheBlock)
+        pool = cls(num_gpu_blocks=n, block_size=block_tokens, cell_size=cell, num_layers=layers,
+                   enable_caching=cfg["enable_caching"], max_cached_blocks=cfg["max_cached_blocks"])
+        assert pool.kv_cache_manager._post_init_done.wait(20)
+        assert pool.null_block.block_id == case["null_block"]
+        live, hits_seen, errors_seen, mapped_peak = {}, 0, 0, 0
+        for op, want in zip(case["ops"], case["records"]):
+            if op[0] == "req":
+                _, rid, hashes, group = op
+                hs = [b"h%06d" % h for h in hashes]
+                hit_blocks = []
+                for h in hs:
+                    got = pool.get_cached_block(h, [group])
+                    if not got:
+                        break
+                    hit_blocks.append(got[0])
+                if hit_blocks:
+                    pool.touch(hit_blocks)
+                    # the point of the test: a hit hands back a block whose CONTENT is what was written for that hash
+                    for h_id, b in zip(hashes, hit_blocks):
+                        for v in _blk_view(raw, b.block_id, block_bytes):
+                            assert int(v[0]) == h_id and int(v[-1]) == ~h_id, (rid, h_id, b.block_id)
+                    hits_seen += len(hit_blocks)
+                need = len(hs) - len(hit_blocks)
+                try:
+                    new = pool.get_new_blocks(need) if need else []
+                except ValueError as e:
+                    assert isinstance(want["r"], str) and want["r"].startswith("ValueError"), (op, want["r"], str(e))
+                    errors_seen += 1
+                    continue
+                assert isinstance(want["r"], dict), (op, want["r"])
+                assert want["r"]["hit"] == len(hit_blocks), (op, want["r"], len(hit_blocks))     # same hits as the reference's pool
+                for h_id, b in zip(hashes[len(hit_blocks):], new):            # "compute" the new blocks: sign them
+                    for v in _blk_view(raw, b.block_id, block_bytes):
+                        v[0] = h_id
+                        v[-1] = ~h_id
+                blocks = hit_blocks + new
+                pool.cache_full_blocks(T.FakeRequest(hs), blocks, len(hit_blocks), len(blocks), 16, group)
+                live[rid] = blocks
+                mapped_peak = max(mapped_peak, capi.get_stats()["pages_mapped"] - capi.get_stats()["pages_unmapped"])
+            elif op[0] == "fin":
+                pool.free_blocks(reversed(live.pop(op[1], [])))
+            elif op[0] == "evict":
+                pool.evict_blocks(set(op[1]))
+            elif op[0] == "reset":
+                assert pool.reset_prefix_cache() == want["r"]
+            elif op[0] == "stat":
+                assert pool.get_num_free_blocks() == want["r"][0]
+            assert pool.get_num_free_blocks() == want["s"][0], (op, pool.get_num_free_blocks(), want["s"][0])
+            assert len(pool._cached_blocks) == want["s"][2]
+        torch.cuda.synchronize()
+        assert hits_seen > 0 or not cfg["enable_caching"]
+        assert mapped_peak > 0
+        for blocks in live.values():
+            pool.free_blocks(reversed(blocks))
+        del pool
+    finally:
+        vmm_ops.shutdown_kvcached()
