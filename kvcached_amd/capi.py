@@ -34,6 +34,8 @@ OPT_BACKGROUND_SHOOTDOWNS = 111  # read-only: TLB invalidations performed by the
 # free pieces inside partly used extents (the waste), the extent size new runs get right now
 OPT_KFD_TLB_FLUSH_ACTIVE, OPT_MAX_EXTENT_PAGES = 118, 119
 OPT_POOL_HELD_PAGES, OPT_POOL_OUT_PAGES, OPT_POOL_FREE_PIECES, OPT_POOL_EXTENT_PAGES_NOW = 120, 121, 122, 123
+# read-only: pages zeroed on their way back to the pool / handed out by map calls that had nothing left to zero (§4.9)
+OPT_PAGES_SCRUBBED, OPT_PAGES_PRESCRUBBED = 125, 126
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _I64P = ctypes.POINTER(ctypes.c_int64)

@@ -28,6 +28,7 @@ void Stats::reset() {
   tlb_shootdowns = shootdown_ns = 0;
   index_launches = 0;
   unmaps_queued = unmaps_cancelled = 0;
+  pages_scrubbed = pages_prescrubbed = 0;
   t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
   vmm.created = vmm.released = vmm.reused = 0;
   std::lock_guard<std::mutex> g(mu);
@@ -86,6 +87,7 @@ GpuContext::GpuContext(int dev) : dev_(dev) {
     throw InvalidError("Invalid page size: " + std::to_string(g_page_size) + " must be a multiple of HIP granularity " +
                        std::to_string(gran));
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&scrub_stream_, hipStreamNonBlocking));
   if (env_bool("KVCACHED_KFD_TLB_FLUSH", true)) {
     std::string why;
     if (!kfd_flush_.open(dev_, &why))
@@ -109,8 +111,12 @@ GpuContext::~GpuContext() {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
+  if (scrub_stream_) (void)hipStreamSynchronize(scrub_stream_); // no fill may be running on an alias that is about to go
   extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
   extent_pools_[1].clear();
+  for (auto &a : arenas_) (void)hipMemAddressFree(a.base, a.size);
+  arenas_.clear();
+  if (scrub_stream_) (void)hipStreamDestroy(scrub_stream_);
   kfd_flush_.close();
   if (uniq_bitmap_) (void)hipFree(uniq_bitmap_);
   if (uniq_header_) (void)hipFree(uniq_header_);
@@ -150,10 +156,32 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
     // (re)made at the first use after an init that changed the extent size: no region exists then, every piece is home
     ExtentDriver d;
     const int dev = dev_;
-    d.create = [dev, page_bytes, exportable](size_t pages) -> phys_handle_t {
+    const bool aliases = k > 1 && options().scrub_on_release.load() != 0; // (k > 1: drm backend, buffers of our own making)
+    d.create = [this, dev, page_bytes, exportable, aliases](size_t pages, uint64_t *tag) -> phys_handle_t {
       if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
         hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-      return vmm_create(dev, pages * page_bytes, exportable, true, (unsigned)pages);
+      const phys_handle_t h = vmm_create(dev, pages * page_bytes, exportable, true, (unsigned)pages);
+      if (tag) *tag = 0;
+      if (tag && aliases) {
+        // The buffer's second, permanent mapping: the address its pages are zeroed through after their slots are gone.
+        // One more ioctl per buffer; failure only means that its pages are zeroed when they are mapped, as before.
+        if (void *bo = DrmVm::instance().find(h)) {
+          const uint64_t va = alias_alloc(pages * page_bytes);
+          if (va && DrmVm::instance().map(bo, reinterpret_cast<void *>(va), pages * page_bytes, 0) == 0)
+            *tag = va;
+          else if (va)
+            alias_free(va, pages * page_bytes);
+        }
+      }
+      return h;
+    };
+    d.prepare_release = [this, page_bytes](phys_handle_t, uint64_t tag, size_t pages) {
+      if (!tag) return;
+      wait_all_scrubs(); // nothing may still be writing through the alias
+      StaleAfter mark;   // a live translation goes away: the invalidation before_release performs covers it
+      if (DrmVm::instance().clear(reinterpret_cast<void *>(tag), pages * page_bytes) != 0)
+        KVC_LOG(LOG_ERROR, "dropping the alias mapping of a buffer failed");
+      alias_free(tag, pages * page_bytes);
     };
     d.release = [](phys_handle_t h) {
       const bool ok = vmm_try_release(h);
@@ -253,12 +281,19 @@ void GpuContext::harvest() {
   std::lock_guard<std::mutex> g(mu_);
   if (inflight_.empty()) return;
   double fill = 0, comp = 0;
+  std::vector<Timed> still;
   for (auto &t : inflight_) {
+    if (hipEventQuery(t.b) == hipErrorNotReady) { // a launch on the other stream that has not finished: next time
+      (void)hipGetLastError();
+      still.push_back(t);
+      continue;
+    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) (t.kind == 0 ? fill : comp) += ms;
+    (void)hipGetLastError();
     free_events_.emplace_back(t.a, t.b);
   }
-  inflight_.clear();
+  inflight_.swap(still);
   std::lock_guard<std::mutex> g2(stats().mu);
   stats().fill_ms += fill;
   stats().compact_ms += comp;
@@ -275,6 +310,58 @@ void GpuContext::zero_fill(void *const *pages, size_t n, size_t page_bytes, hipS
     stats().fill_launches++;
     stats().fill_bytes += (int64_t)k * (int64_t)page_bytes;
   }
+}
+
+uint64_t GpuContext::scrub(const uint64_t *alias_addrs, size_t n, size_t page_bytes) {
+  std::vector<void *> ptrs;
+  ptrs.reserve(n);
+  for (size_t i = 0; i < n; ++i)
+    if (alias_addrs[i]) ptrs.push_back(reinterpret_cast<void *>(alias_addrs[i]));
+  if (ptrs.empty()) return 0;
+  std::lock_guard<std::mutex> g(scrub_mu_);
+  bind();
+  zero_fill(ptrs.data(), ptrs.size(), page_bytes, scrub_stream_);
+  stats().pages_scrubbed += (int64_t)ptrs.size();
+  return scrub_issued_.fetch_add(1) + 1;
+}
+
+void GpuContext::wait_scrub(uint64_t ticket) {
+  if (!ticket || scrub_done_.load() >= ticket) return;
+  const uint64_t covered = scrub_issued_.load(); // every scrub launched so far is ahead of the sync below
+  HIP_CHECK(hipStreamSynchronize(scrub_stream_));
+  uint64_t cur = scrub_done_.load();
+  while (cur < covered && !scrub_done_.compare_exchange_weak(cur, covered)) {
+  }
+  harvest();
+}
+
+uint64_t GpuContext::alias_alloc(size_t bytes) {
+  std::lock_guard<std::mutex> g(arena_mu_);
+  auto it = alias_free_.find(bytes);
+  if (it != alias_free_.end() && !it->second.empty()) {
+    const uint64_t va = it->second.back();
+    it->second.pop_back();
+    return va;
+  }
+  constexpr size_t kArena = 64ull << 30;
+  if (arenas_.empty() || arenas_.back().size - arenas_.back().used < bytes) {
+    void *p = nullptr;
+    const size_t want = std::max(kArena, bytes);
+    if (hipMemAddressReserve(&p, want, kBasePage, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    arenas_.push_back(Arena{static_cast<char *>(p), want, 0});
+  }
+  Arena &a = arenas_.back();
+  const uint64_t va = reinterpret_cast<uint64_t>(a.base + a.used);
+  a.used += bytes;
+  return va;
+}
+
+void GpuContext::alias_free(uint64_t va, size_t bytes) {
+  std::lock_guard<std::mutex> g(arena_mu_);
+  alias_free_[bytes].push_back(va);
 }
 
 void GpuContext::compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
@@ -814,6 +901,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().phys_chunk_pages = std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 32)));
   options().extent_waste_pct = std::min<int64_t>(100, std::max<int64_t>(0, env_i64("KVCACHED_EXTENT_WASTE_PCT", 5)));
   options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 1024)) << 20;
+  options().scrub_on_release = env_bool("KVCACHED_SCRUB_ON_RELEASE", true) ? 1 : 0;
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -1027,9 +1115,10 @@ void KvAllocator::flush_all_unmaps() {
     for (auto &kv : g_allocators) all.push_back(kv.second.get());
   }
   for (auto *a : all) a->flush_unmaps();
-  if (GpuContext *ctx = gpu()) { // ... and no invalidation is left owed or in flight
+  if (GpuContext *ctx = gpu()) { // ... and no invalidation is left owed or in flight, no page still being zeroed
     ctx->bind();
     ctx->ensure_flushed();
+    ctx->wait_all_scrubs();
   }
 }
 
@@ -1471,7 +1560,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // invalidation is owed per chunk - compat mode, deferred unmaps - larger chunks mean fewer of them).
   const size_t chunk = (size_t)std::max<int64_t>(1, options().fill_chunk_slots.load());
   const size_t n_total = slots.size();
-  size_t next_cut = n_total >= 512 ? std::min(chunk, n_total - std::max<size_t>(128, n_total / 4)) : chunk;
+  // (with run-sized extents the driver calls of a whole batch take less time than a launch: nothing to hide a first
+  // instalment behind, and one large launch is the more efficient one)
+  size_t next_cut = (n_total >= 512 && !pool->multi_page()) ? std::min(chunk, n_total - std::max<size_t>(128, n_total / 4)) : chunk;
+  uint64_t max_ticket = 0; // pages that were zeroed on their way back: nothing to launch, only that scrub to wait for
   auto launch_pending = [&](bool all) {
     size_t i = 0;
     while (pending.size() - i >= next_cut || (all && i < pending.size())) {
@@ -1568,7 +1660,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       done.push_back(s);
       if (!needs_access) { // mapped readable+writable in one ioctl (drm backend): straight to the fill queue
         if (always_flush) dirty_tlb = true;
-        if (fill) {
+        if (fill && ph.scrub_ticket) {
+          max_ticket = std::max(max_ticket, ph.scrub_ticket);
+          stats().pages_prescrubbed++;
+        } else if (fill) {
           pending.push_back(va);
           launch_pending(false);
         }
@@ -1586,6 +1681,15 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       std::sort(fresh.begin(), fresh.end(), [](const Slot &a, const Slot &b) {
         return a.region != b.region ? a.region < b.region : a.index < b.index;
       });
+      // the same slot listed twice in one call: the reference logs "already mapped" for the second and goes on (ftensor.cpp:104-107)
+      for (size_t i = 1; i < fresh.size();) {
+        if (fresh[i].region == fresh[i - 1].region && fresh[i].index == fresh[i - 1].index) {
+          KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", fresh[i].index);
+          fresh.erase(fresh.begin() + (long)i);
+        } else {
+          ++i;
+        }
+      }
       std::vector<Phys> got(kMaxExtentPages);
       for (size_t i = 0; i < fresh.size();) {
         size_t j = i + 1;
@@ -1613,7 +1717,11 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
             r.seq[s.index] = got[k].seq;
             r.mapped[s.index] = 1;
             done.push_back(s);
-            if (fill) pending.push_back(r.base + s.index * ps);
+            if (fill && got[k].scrub_ticket) {
+              max_ticket = std::max(max_ticket, got[k].scrub_ticket);
+              stats().pages_prescrubbed++;
+            } else if (fill)
+              pending.push_back(r.base + s.index * ps);
           }
           if (always_flush) dirty_tlb = true;
           if (fill) launch_pending(false);
@@ -1626,6 +1734,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     ctx->ensure_flushed(); // nothing may reach the new pages through a stale translation
     const int64_t ts = now_ns();
     if (launched) ctx->sync(nullptr);
+    ctx->wait_scrub(max_ticket);
     stats().t_sync += now_ns() - ts;
   } catch (...) {
     // leave the regions as they were before this call; PageAllocator rolls the page ids back
@@ -1812,7 +1921,14 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
     if (!vmm_try_release(h)) KVC_LOG(LOG_ERROR, "releasing an imported handle failed");
   }
   const int64_t tr0 = now_ns();
-  pool->release_batch(u.own.data(), u.own.size());
+  // Zero the pages on their way back: the fill is queued (through the alias mappings of their buffers) BEFORE they are on
+  // offer again, and whoever gets them next only waits for that ticket (GpuContext::scrub).
+  uint64_t ticket = 0;
+  if (options().zero_fill.load() && options().scrub_on_release.load() && pool->multi_page() && !u.own.empty()) {
+    std::vector<uint64_t> addrs(u.own.size());
+    if (pool->scrub_addresses(u.own.data(), u.own.size(), addrs.data())) ticket = ctx->scrub(addrs.data(), addrs.size(), u.page_size);
+  }
+  pool->release_batch(u.own.data(), u.own.size(), ticket);
   stats().t_release += now_ns() - tr0;
   stats().pages_unmapped += u.n;
 }

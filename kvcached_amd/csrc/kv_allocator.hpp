@@ -11,6 +11,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -37,6 +38,7 @@ struct Options {
   std::atomic<int64_t> phys_chunk_pages{32};     // drm backend: a run of adjacent slots is backed by ONE buffer of up to this many pages (1 = off)
   std::atomic<int64_t> extent_waste_pct{5};      // ... and new extents shrink while free pieces of partly used ones exceed this share of the pages in use
   std::atomic<int64_t> phys_reserve_bytes{0};    // idle physical memory the housekeeping thread keeps ready (pre-created, never below it)
+  std::atomic<int64_t> scrub_on_release{1};      // drm backend: pages are zeroed (through an alias mapping) when they come back, not when they go out
   std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
@@ -54,6 +56,7 @@ struct Stats {
   std::atomic<int64_t> compact_launches{0}, compact_bytes{0};
   std::atomic<int64_t> tlb_shootdowns{0}, shootdown_ns{0};
   std::atomic<int64_t> index_launches{0};
+  std::atomic<int64_t> pages_scrubbed{0}, pages_prescrubbed{0}; // zeroed on their way back / handed out without a fill of their own (options 125, 126)
   std::atomic<int64_t> unmaps_queued{0}, unmaps_cancelled{0}; // async unmap: slots queued / re-backed before the reclaimer got to them
   // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
   std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
@@ -91,6 +94,18 @@ public:
   void compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
                size_t block_bytes, hipStream_t s);
   void sync(hipStream_t s); // hipStreamSynchronize + harvest event timings
+  // ---- zeroing pages on their way BACK (drm backend, extents with an alias mapping).
+  // A page handed out by map_slots must read zero. Filling it there puts 0.3 us per page of GPU time between the
+  // driver calls and the caller; filling it when it is given back - through a second, permanent mapping of its buffer
+  // that only the library knows, on a stream of its own - lets that run while the host does whatever comes next.
+  // scrub(): launches the fill on the given alias addresses (0 = skip) and returns its ticket; wait_scrub(t): returns
+  // once scrub t has finished (no-op if it has). Tickets are issued in launch order on one stream.
+  uint64_t scrub(const uint64_t *alias_addrs, size_t n, size_t page_bytes);
+  void wait_scrub(uint64_t ticket);
+  void wait_all_scrubs() { wait_scrub(scrub_issued_.load()); }
+  // VA for alias mappings (never handed to anybody): carved from arenas reserved 64 GiB at a time
+  uint64_t alias_alloc(size_t bytes);
+  void alias_free(uint64_t va, size_t bytes);
   // block id <-> token index glue (index_kernels.hip); ids are HOST arrays, everything else device memory
   void expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s);
   void alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
@@ -141,6 +156,16 @@ private:
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
   std::vector<ExtentPool *> all_pools();
   KfdTlbFlush kfd_flush_;
+  hipStream_t scrub_stream_ = nullptr;
+  std::mutex scrub_mu_; // launch order = ticket order
+  std::atomic<uint64_t> scrub_issued_{0}, scrub_done_{0};
+  struct Arena {
+    char *base;
+    size_t size, used;
+  };
+  std::mutex arena_mu_;
+  std::vector<Arena> arenas_;
+  std::map<size_t, std::vector<uint64_t>> alias_free_; // by size: extents come in a handful of sizes
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
   // unique_block_ids scratch (grow-only; bitmap all-zero and header reset between calls)

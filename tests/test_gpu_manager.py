@@ -46,10 +46,14 @@ def test_golden_small_traces_executed_on_gpu(idx):
         got = T.replay(ad, case["ops"], full=True)
         for i, (g, want) in enumerate(zip(got, case["records"])):
             assert g == want, f"{case['name']} op {i} {case['ops'][i]}"
+        capi.flush_unmaps()
         st = capi.get_stats()
-        assert st["pages_mapped"] > 0 and st["fill_bytes"] == st["pages_mapped"] * (
-            T.PAGE * (case["config"]["num_layers"] * case["config"]["num_kv_buffers"]
-                      if case["config"]["contiguous"] else 1))
+        page = T.PAGE * (case["config"]["num_layers"] * case["config"]["num_kv_buffers"] if case["config"]["contiguous"] else 1)
+        # every page a map call handed out was zeroed exactly once for that use: by the map call itself (fresh memory), or on
+        # its way back to the pool after its previous use
+        scrubbed, prescrubbed = capi.get_option(capi.OPT_PAGES_SCRUBBED), capi.get_option(capi.OPT_PAGES_PRESCRUBBED)
+        assert st["pages_mapped"] > 0 and st["fill_bytes"] == (st["pages_mapped"] - prescrubbed + scrubbed) * page
+        assert prescrubbed <= scrubbed <= st["pages_unmapped"]
     finally:
         ad.close()
 

@@ -465,6 +465,53 @@ def test_a_batch_of_adjacent_slots_is_a_handful_of_ioctls(vmm):
     assert ops.unmap_from_kv_tensors(offs2)
 
 
+def test_pages_are_zeroed_on_their_way_back_not_on_their_way_out(vmm, monkeypatch):
+    """DESIGN.md §4.9. With the drm backend every physical buffer keeps a second, private mapping; when its pages are given
+    back the fill kernel is queued through that alias on a stream of the library's own, and the map call that hands them
+    out again launches nothing - it waits for that scrub (usually long finished) and returns: the zero fill has left the
+    allocation path. Fresh memory from the driver is still filled by the map call that first uses it."""
+    epp = PAGE // 2
+    for scrub in (True, False):
+        monkeypatch.setenv("KVCACHED_SCRUB_ON_RELEASE", "true" if scrub else "false")
+        ops, capi, ts = _setup(vmm, layers=1, per_layer=512 * PAGE, backfill=False, kv=1, unified=True)
+        if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+            pytest.skip("needs the drm backend with pages straight from KFD")
+        t = ts[0]
+        offs = [i * PAGE for i in range(0, 96)] + [i * PAGE for i in (200, 202, 204)]
+        capi.reset_stats()
+        assert ops.map_to_kv_tensors(offs)
+        st = capi.get_stats()
+        assert st["fill_bytes"] == len(offs) * PAGE and st["handles_created"] == len(offs)     # fresh memory: filled by the map
+        for o in offs:
+            assert int(torch.count_nonzero(t[o // 2:o // 2 + epp])) == 0
+            t[o // 2:o // 2 + epp] = 0x5a5a
+        torch.cuda.synchronize()
+        before_unmap = capi.get_stats()
+        assert ops.unmap_from_kv_tensors(offs)
+        capi.flush_unmaps()
+        after_unmap = capi.get_stats()
+        assert after_unmap["fill_bytes"] - before_unmap["fill_bytes"] == (len(offs) * PAGE if scrub else 0)   # the scrub ran behind the unmap
+        offs2 = [(256 + i) * PAGE for i in range(0, 96)] + [(400 + 2 * i) * PAGE for i in range(3)]   # other slots, same pages
+        assert ops.map_to_kv_tensors(offs2)
+        st = capi.get_stats()
+        assert st["handles_reused"] == len(offs2) and st["handles_created"] == len(offs)       # not one new page
+        assert st["fill_bytes"] - after_unmap["fill_bytes"] == (0 if scrub else len(offs2) * PAGE)   # nothing launched by this map
+        for o in offs2:
+            assert int(torch.count_nonzero(t[o // 2:o // 2 + epp])) == 0                      # and still: zero, not 0x5a5a
+        # a page that comes back while zero fill is switched off is not trusted later
+        capi.set_option(capi.OPT_ZERO_FILL, 0)
+        t[offs2[0] // 2:offs2[0] // 2 + epp] = 0x1111
+        torch.cuda.synchronize()
+        assert ops.unmap_from_kv_tensors(offs2[:1])
+        capi.set_option(capi.OPT_ZERO_FILL, 1)
+        assert ops.map_to_kv_tensors([500 * PAGE])
+        assert int(torch.count_nonzero(t[500 * epp:501 * epp])) == 0
+        assert ops.unmap_from_kv_tensors(offs2[1:] + [500 * PAGE])
+        ops.shutdown_kvcached()
+        st = capi.get_stats()
+        assert st["handles_created"] == st["handles_released"]
+
+
 _TLB_CHILD = r"""
 import os, sys
 sys.path.insert(0, %r)
