@@ -173,24 +173,37 @@ public:
     const bool pressure = drv_.under_pressure && drv_.under_pressure();
     {
       std::lock_guard<std::mutex> g(mu_);
-      for (size_t i = 0; i < n; ++i) {
-        const phys_handle_t h = key_of(ps[i].h);
+      // pieces of one extent are handled together (one lookup, one re-bucketing): a batch lists a few dozen extents
+      std::vector<std::pair<phys_handle_t, unsigned>> order(n);
+      for (size_t i = 0; i < n; ++i) order[i] = {key_of(ps[i].h), idx_of(ps[i].h)};
+      std::sort(order.begin(), order.end());
+      for (size_t i = 0; i < n;) {
+        const phys_handle_t h = order[i].first;
+        size_t j = i;
+        uint64_t bits = 0;
+        bool twice = false;
+        for (; j < n && order[j].first == h; ++j) {
+          const uint64_t bit = order[j].second < 64 ? 1ull << order[j].second : 0;
+          twice = twice || bit == 0 || (bits & bit);
+          bits |= bit;
+        }
+        const size_t cnt = j - i;
+        i = j;
         auto it = tracked_.find(h);
-        const uint64_t bit = 1ull << idx_of(ps[i].h);
-        if (it == tracked_.end() || (it->second.free_mask & bit) || idx_of(ps[i].h) >= it->second.n) {
-          ++bad_releases_; // a piece of an unknown extent, or one that is not out: never corrupt the masks
+        if (it == tracked_.end() || twice || (bits & it->second.free_mask) || (bits & ~full_mask(it->second.n))) {
+          bad_releases_ += cnt; // pieces of an unknown extent, listed twice, or not out: never corrupt the masks
           continue;
         }
         Extent &e = it->second;
-        e.free_mask |= bit;
+        e.free_mask |= bits;
         if (scrub_ticket && e.tag) {
-          e.clean_mask |= bit;
+          e.clean_mask |= bits;
           e.ticket = std::max(e.ticket, scrub_ticket);
         } else {
-          e.clean_mask &= ~bit;
+          e.clean_mask &= ~bits;
         }
-        ++free_pieces_;
-        --out_pieces_;
+        free_pieces_ += cnt;
+        out_pieces_ -= cnt;
         if (e.free_mask == full_mask(e.n)) { // the extent is whole again: idle, ours to reuse or to give back
           unbucket_locked(h, e);
           free_pieces_ -= e.n;
@@ -344,6 +357,7 @@ private:
     uint8_t n;
     bool used;
     uint64_t tag, clean_mask, ticket;
+    uint64_t order = 0; // key in idle_n_
   };
   struct Victim {
     phys_handle_t h;
@@ -410,11 +424,15 @@ private:
   bool take_idle_locked(unsigned size, unsigned take, Phys *out, bool *recycled) {
     auto &s = idle_n_[size];
     if (s.empty()) return false;
-    const auto key = *std::prev(s.end());
-    s.erase(std::prev(s.end()));
-    idle_all_.erase(key);
+    // Which one? A pool of single pages hands out the youngest buffer (ROCr's creation cost is O(live handles) with the
+    // oldest cheapest to release: they stay at the eviction end). A pool of extents hands out the one that has been idle
+    // longest: its pages were zeroed on their way back, and the longer ago that was queued the surer it has finished.
+    const auto pos = kmax_cfg_ > 1 ? s.begin() : std::prev(s.end());
+    const auto key = *pos;
+    s.erase(pos);
     const phys_handle_t h = key.second;
     const IdleInfo info = idle_info_[h];
+    idle_all_.erase({info.seq, h});
     idle_info_.erase(h);
     idle_pages_ -= size;
     low_water_ = std::min(low_water_, idle_pages_);
@@ -431,8 +449,9 @@ private:
     take_pieces_locked(h, e, 0, take, out, recycled);
     return true;
   }
-  void idle_insert_locked(phys_handle_t h, const IdleInfo &info) {
-    idle_n_[info.n].insert({info.seq, h});
+  void idle_insert_locked(phys_handle_t h, IdleInfo info) {
+    info.order = kmax_cfg_ > 1 ? ++idle_stamp_ : info.seq; // extents: by the time they became idle; single pages: by creation
+    idle_n_[info.n].insert({info.order, h});
     idle_all_.insert({info.seq, h});
     idle_info_[h] = info;
     idle_pages_ += info.n;
@@ -443,7 +462,7 @@ private:
     idle_all_.erase(idle_all_.begin());
     const IdleInfo info = idle_info_[key.second];
     idle_info_.erase(key.second);
-    idle_n_[info.n].erase(key);
+    idle_n_[info.n].erase({info.order, key.second});
     idle_pages_ -= info.n;
     victims->push_back(Victim{key.second, key.first, info.n, info.tag});
     return true;
@@ -488,7 +507,7 @@ private:
   std::atomic<double> waste_frac_{0.05};
   std::atomic<bool> defer_eviction_{false};
   std::mutex mu_;
-  uint64_t next_seq_ = 0;
+  uint64_t next_seq_ = 0, idle_stamp_ = 0;
   unsigned last_created_pages_ = 1;
   size_t handed_out_since_clamp_ = 0;
   size_t recover_pages_ = 4096; // 8 GiB of 2 MiB pages handed out between two steps back up
@@ -499,7 +518,7 @@ private:
   size_t bad_releases_ = 0, failed_releases_ = 0;
   std::unordered_map<phys_handle_t, Extent> tracked_;          // extents with at least one piece handed out
   std::set<phys_handle_t> by_run_[kMaxExtentPages + 1];         // ... bucketed by their longest free run
-  std::set<std::pair<uint64_t, phys_handle_t>> idle_n_[kMaxExtentPages + 1]; // whole idle extents by size, creation order
+  std::set<std::pair<uint64_t, phys_handle_t>> idle_n_[kMaxExtentPages + 1]; // whole idle extents by size, in hand-out order (IdleInfo::order)
   std::set<std::pair<uint64_t, phys_handle_t>> idle_all_;       // ... all of them, oldest first (eviction order)
   std::unordered_map<phys_handle_t, IdleInfo> idle_info_;
   size_t low_water_ = 0;        // smallest idle_pages_ since window_start_ns_

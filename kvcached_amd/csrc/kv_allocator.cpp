@@ -528,9 +528,31 @@ void GpuContext::tlb_shootdown() {
   do_shootdown();
 }
 
+void GpuContext::ensure_flushed_through(uint64_t epoch) {
+  // (at most two rounds: an invalidation that was already in flight when the translation went away does not count,
+  // the one after it does)
+  for (int i = 0; i < 4 && !flushed_through(epoch); ++i) {
+    std::lock_guard<std::mutex> g(flush_mu_);
+    if (flushed_through(epoch)) break;
+    do_shootdown();
+  }
+}
+
 void GpuContext::do_shootdown() {
   tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
-  if (!options().tlb_shootdown.load()) return;
+  const uint64_t epoch = flush_started_.fetch_add(1) + 1;
+  struct Done {
+    std::atomic<uint64_t> &d;
+    uint64_t e;
+    bool ok = false;
+    ~Done() {
+      if (ok) d.store(std::max(d.load(), e)); // (serialised by flush_mu_)
+    }
+  } done{flush_done_, epoch};
+  if (!options().tlb_shootdown.load()) {
+    done.ok = true;
+    return;
+  }
   static const bool broken_for_test = env_bool("KVCACHED_TEST_BREAK_TLB_FLUSH", false); // hook: the init self test must notice
   const int64_t t0 = now_ns();
   if (broken_for_test) {
@@ -555,6 +577,7 @@ void GpuContext::do_shootdown() {
       HIP_CHECK(hipFree(p));
     }
   }
+  done.ok = true;
   stats().tlb_shootdowns++;
   if (tl_background_thread) background_shootdowns()++;
   stats().shootdown_ns += now_ns() - t0;
@@ -898,10 +921,11 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().async_shootdown = env_bool("KVCACHED_ASYNC_SHOOTDOWN", true) ? 1 : 0;
   options().hip_reg_group_mb = std::max<int64_t>(0, env_i64("KVCACHED_HIP_REG_GROUP_MB", 64));
   options().clear_run_slots = std::max<int64_t>(0, env_i64("KVCACHED_DRM_CLEAR_RUN", 16));
-  options().phys_chunk_pages = std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 32)));
+  options().phys_chunk_pages = std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 64)));
   options().extent_waste_pct = std::min<int64_t>(100, std::max<int64_t>(0, env_i64("KVCACHED_EXTENT_WASTE_PCT", 5)));
   options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 1024)) << 20;
   options().scrub_on_release = env_bool("KVCACHED_SCRUB_ON_RELEASE", true) ? 1 : 0;
+  options().map_waits_for_all_flushes = env_bool("KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES", false) ? 1 : 0;
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -1143,6 +1167,7 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
   }
   r->handle.assign(r->num_slots(), phys_handle_t{});
   r->seq.assign(r->num_slots(), 0);
+  r->stale_epoch.assign(r->num_slots(), 0);
   r->mapped.assign(r->num_slots(), 0);
   r->registered.assign(r->num_slots(), 0);
   r->reg_group = std::max<size_t>(1, (size_t)std::max<int64_t>(0, options().hip_reg_group_mb.load()) * (1u << 20) / r->page_size);
@@ -1493,6 +1518,7 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
       if (void *bo = vmm_direct_bo(r.handle[s.index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
     stats().t_unmap += now_ns() - t0;
     r.mapped[s.index] = 0;
+    r.stale_epoch[s.index] = ctx_->next_flush_epoch();
     *out = Phys{r.handle[s.index], r.seq[s.index]};
     g_pending_unmap_bytes -= std::min(ps, g_pending_unmap_bytes.load());
     stats().pages_unmapped++;
@@ -1552,6 +1578,18 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // map of an unbacked slot whose last unmap was invalidated needs nothing (KVCACHED_MAP_SHOOTDOWN=always restores it).
   const bool always_flush = options().map_shootdown_always.load() != 0;
   bool dirty_tlb = ctx->tlb_owed(); // an invalidation is owed before anything of this batch is touched
+  // ... but only the invalidations that cover THESE slots' last unmaps have to be waited for: a stale translation of some
+  // other address cannot shadow a mapping made here, and it is gone a moment later anyway (every unmap batch has its
+  // invalidation under way on the context's thread). KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES=true restores the blanket wait.
+  uint64_t need_epoch = 0;
+  for (auto &s : slots) need_epoch = std::max(need_epoch, s.region->stale_epoch[s.index]);
+  const bool blanket = options().map_waits_for_all_flushes.load() != 0;
+  auto flush_for_batch = [&]() {
+    if (blanket || always_flush)
+      ctx->ensure_flushed();
+    else
+      ctx->ensure_flushed_through(need_epoch);
+  };
   // Fill launches: the kernel for the slots mapped so far runs while the host issues the driver calls for the rest, so
   // only the LAST launch is exposed. Large launches are more efficient (ramp and tail are ~10 us whatever the size:
   // 6.8 TB/s at 2 GiB, 6.4 at 512 MiB), the exposed one should be short: a batch of n >= 512 slots is filled as
@@ -1570,7 +1608,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       const size_t end = i + std::min(next_cut, pending.size() - i);
       if (always_flush && dirty_tlb) tlb_stale().store(true);
       dirty_tlb = false;
-      ctx->ensure_flushed(); // only if an unmap (ours in this batch, or an earlier one still owed) has happened since the last one
+      flush_for_batch(); // only if one of these slots (or, compat mode, an alias replaced in this batch) is still owed one
       for (; i < end; i += std::min<size_t>(kMaxPtrsPerLaunch, end - i))
         ctx->zero_fill(pending.data() + i, std::min<size_t>(kMaxPtrsPerLaunch, end - i), ps, nullptr);
       launched = true;
@@ -1619,6 +1657,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (r.backfilled) {
         vmm_unmap(va, ps);
         dirty_tlb = true; // the alias's translation is live
+        need_epoch = ctx->next_flush_epoch();
       }
       int64_t t1 = now_ns();
       bool recycled = false;
@@ -1636,6 +1675,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       } else if (steal_pending(ps, &ph)) { // async unmap: take the page of a released slot instead of creating one
         recycled = true;
         dirty_tlb = true;
+        need_epoch = ctx->next_flush_epoch(); // (the page's old address was live a moment ago: conservative)
       } else {
         (void)pool->acquire_run(1, &ph, &recycled, true);
       }
@@ -1699,7 +1739,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           const int64_t t1 = now_ns();
           bool recycled = false;
           size_t n = pool->acquire_run(j - i, got.data(), &recycled, false);
-          if (n == 0 && steal_pending(ps, &got[0])) n = 1; // (its unmap has set tlb_stale: flushed before the fill)
+          if (n == 0 && steal_pending(ps, &got[0])) {
+            n = 1; // (its unmap has set tlb_stale: flushed before the fill)
+            need_epoch = ctx->next_flush_epoch();
+          }
           if (n == 0) n = pool->acquire_run(j - i, got.data(), &recycled, true);
           const int64_t t2 = now_ns();
           char *va = r.base + fresh[i].index * ps;
@@ -1731,7 +1774,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     }
     if (fill) launch_pending(true);
     if (always_flush && dirty_tlb) tlb_stale().store(true);
-    ctx->ensure_flushed(); // nothing may reach the new pages through a stale translation
+    flush_for_batch(); // nothing may reach the new mappings through a stale translation of their own addresses
     const int64_t ts = now_ns();
     if (launched) ctx->sync(nullptr);
     ctx->wait_scrub(max_ticket);
@@ -1804,6 +1847,8 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   // invalidated. An extent that loses ALL its mapped pages in this batch leaves nothing behind to rewrite.
   ExtentPool *xpool = ctx->extents(ps, exportable_);
   std::vector<phys_handle_t> touched;
+  std::vector<std::pair<KvRegion *, size_t>> gone;
+  gone.reserve(slots.size());
   // drm backend, lazy regions: slots of this batch that are neighbours in VA go in runs - one CLEAR ioctl per run of up
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
@@ -1860,6 +1905,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     else
       u.imported.push_back(r.handle[s.index]);
     r.mapped[s.index] = 0;
+    gone.emplace_back(&r, s.index);
     ++u.n;
     if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
     if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
@@ -1887,6 +1933,10 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       i = j;
     }
     tlb_stale().store(true);
+  }
+  { // every driver call that removed or rewrote a translation has returned: the next invalidation to START covers them all
+    const uint64_t epoch = ctx->next_flush_epoch();
+    for (auto &g : gone) g.first->stale_epoch[g.second] = epoch;
   }
 }
 

@@ -35,9 +35,10 @@ struct Options {
   std::atomic<int64_t> async_shootdown{1};       // with a housekeeping thread around, unmap leaves its TLB invalidation to it
   std::atomic<int64_t> hip_reg_group_mb{64};     // hybrid/drm: VA introduced to HIP per hipMemMap (0 = slot by slot)
   std::atomic<int64_t> clear_run_slots{16};      // drm backend: unmap runs of adjacent slots with one CLEAR ioctl (0 = off)
-  std::atomic<int64_t> phys_chunk_pages{32};     // drm backend: a run of adjacent slots is backed by ONE buffer of up to this many pages (1 = off)
+  std::atomic<int64_t> phys_chunk_pages{64};     // drm backend: a run of adjacent slots is backed by ONE buffer of up to this many pages (1 = off)
   std::atomic<int64_t> extent_waste_pct{5};      // ... and new extents shrink while free pieces of partly used ones exceed this share of the pages in use
   std::atomic<int64_t> phys_reserve_bytes{0};    // idle physical memory the housekeeping thread keeps ready (pre-created, never below it)
+  std::atomic<int64_t> map_waits_for_all_flushes{0}; // 1 = a map batch waits for every invalidation owed, not only those of its own slots
   std::atomic<int64_t> scrub_on_release{1};      // drm backend: pages are zeroed (through an alias mapping) when they come back, not when they go out
   std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
@@ -129,6 +130,13 @@ public:
   // another thread's invalidation is in flight waits for it instead of issuing a second one.
   void ensure_flushed();
   void flush_deferred_shootdown() { ensure_flushed(); }
+  // Invalidations are numbered. A translation removed NOW is covered by the first invalidation that starts from now on:
+  // next_flush_epoch() (read after the driver's unmap call has returned) is its number, and flushed_through(e) says
+  // whether that one has finished. A map batch only has to wait for the invalidations that cover ITS slots
+  // (KvRegion::stale_epoch) - a stale translation of some other address cannot shadow a mapping made here.
+  uint64_t next_flush_epoch() const { return flush_started_.load() + 1; }
+  bool flushed_through(uint64_t epoch) const { return flush_done_.load() >= epoch; }
+  void ensure_flushed_through(uint64_t epoch);
   // Have this context's own thread do ensure_flushed() right away (started on first use): the unmap path's 0.3-0.5 ms
   // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
   // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
@@ -147,6 +155,7 @@ private:
   int dev_;
   hipStream_t stream_ = nullptr;
   std::mutex flush_mu_; // serialises TLB invalidations
+  std::atomic<uint64_t> flush_started_{0}, flush_done_{0};
   std::thread flusher_;
   std::mutex fl_mu_;
   std::condition_variable fl_cv_;
@@ -191,6 +200,7 @@ struct KvRegion {
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
+  std::vector<uint64_t> stale_epoch;   // per slot: the TLB invalidation (GpuContext::next_flush_epoch) that covers its last unmap
   // hybrid/drm backends: slots HIP has been told about (placeholder mapping made and removed again). Registration
   // happens in units of `reg_group` consecutive slots (64 MiB of VA per hipMemMap; the slots behind the last full
   // group one by one), and the placeholder handles are HIP handles of the unit's size, one per 4096 units so that

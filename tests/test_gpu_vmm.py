@@ -182,10 +182,12 @@ def test_lazy_mode_without_backfill(vmm):
 
 def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     """KVC_OPT_DEFER_UNMAP_SHOOTDOWN in lazy mode: an unmap batch whose handles all return to the pool performs no
-    TLB invalidation of its own; the next map batch invalidates before anything touches
-    the recycled pages, and handles that leave the pool for the driver are preceded by one. Whatever the slot a
-    recycled (dirty) handle lands on, reads see zeros first and every page stays private. A map batch with nothing
-    owed (the very first one here) invalidates nothing: a translation that was invalid is never cached."""
+    TLB invalidation of its own; a later map batch invalidates - before anything touches its pages - exactly when it
+    re-backs a slot whose last unmap is still owed one (a stale translation of some OTHER address cannot shadow a
+    mapping made here: the per-slot epochs of DESIGN.md §4.3), and handles that leave the pool for the driver are
+    preceded by one. Whatever the slot a recycled (dirty) handle lands on, reads see zeros first and every page stays
+    private. A map batch with nothing owed (the very first one here) invalidates nothing: a translation that was
+    invalid is never cached."""
     ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=False, kv=1, unified=True)
     assert capi.get_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN) == 0          # off by default
     capi.set_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN, 1)
@@ -195,13 +197,17 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     rng = random.Random(0)
     live = {}
     capi.reset_stats()
-    owed = False
-    for r in range(8):
-        slots = rng.sample([s for s in range(32) if s not in live], rng.randint(3, 8))   # recycled handles, new slots
+    owed = set()                                                         # slots unmapped since the last invalidation
+    seen_both = set()
+    for r in range(12):
+        slots = rng.sample([s for s in range(32) if s not in live], rng.randint(3, 8))   # recycled handles, other slots
         n0 = capi.get_stats()["tlb_shootdowns"]
         assert ops.map_to_kv_tensors([s * PAGE for s in slots])
-        assert capi.get_stats()["tlb_shootdowns"] == n0 + int(owed)
-        owed = False
+        needs = bool(owed & set(slots))
+        assert capi.get_stats()["tlb_shootdowns"] == n0 + int(needs), (r, sorted(owed), slots)
+        seen_both.add(needs)
+        if needs:
+            owed.clear()                                                 # one invalidation covers every unmap before it
         for s in slots:
             page = t[s * epp:(s + 1) * epp]
             assert int(torch.count_nonzero(page)) == 0, (r, s)          # recycled handles were dirty
@@ -214,9 +220,10 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
         n1 = capi.get_stats()["tlb_shootdowns"]
         assert ops.unmap_from_kv_tensors([s * PAGE for s in victims])
         assert capi.get_stats()["tlb_shootdowns"] == n1                  # deferred
-        owed = True
+        owed |= set(victims)
         for s in victims:
             live.pop(s)
+    assert seen_both == {True, False}                                    # the trace exercised both kinds of map batch
     # the pool shrinks to nothing: the owed invalidation happens before the first handle goes to the driver
     st0 = capi.get_stats()
     capi.set_option(capi.OPT_POOL_BYTES, 0)
@@ -224,6 +231,7 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
     assert ops.unmap_from_kv_tensors([s * PAGE for s in last])
     st1 = capi.get_stats()
     assert st1["handles_released"] > st0["handles_released"] and st1["tlb_shootdowns"] == st0["tlb_shootdowns"] + 1
+    assert capi.get_option(capi.OPT_POOL_HELD_PAGES) == 0
     # switched off, every unmap invalidates by itself
     capi.set_option(capi.OPT_POOL_BYTES, 1 << 30)
     capi.set_option(capi.OPT_DEFER_UNMAP_SHOOTDOWN, 0)
