@@ -571,7 +571,8 @@ def main():
                     "extents_up_to_64_pages": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "64"}),
                     "unmap_waits_for_its_own_tlb_invalidation": V(env={"KVCACHED_ASYNC_SHOOTDOWN": "false"}),
                     "tlb_flush_through_hipMalloc_instead_of_kfd": V(env={"KVCACHED_KFD_TLB_FLUSH": "false"}),
-                    "compat_zero_backfill_sharded": V(mode="compat", n=8),
+                    "compat_zero_extent": V(mode="compat"),
+                    "compat_zero_backfill_sharded": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false"}),
                     "hybrid_backend_same_cycle": V(be="hybrid"),
                     "hip_backend_same_cycle": V(be="hip"),
                     "hip_backend_compat_zero_backfill_sharded": V(mode="compat", be="hip", n=8),
@@ -607,7 +608,7 @@ def main():
                                 os.environ[k] = v
                 line["variants"] = variants
                 # the reference's semantics (unbacked VA reads as zeros) next to the headline, not only among the variants
-                line["compat_mode_GBps"] = variants.get("compat_zero_backfill_sharded", {}).get("GBps")
+                line["compat_mode_GBps"] = variants.get("compat_zero_extent", {}).get("GBps")
                 try:
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)
                 except Exception as e:

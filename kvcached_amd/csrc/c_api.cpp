@@ -179,6 +179,11 @@ int64_t kvc_get_option(int opt) {
     GpuContext *ctx = KvAllocator::gpu();
     return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().extent_pages_now : 0;
   }
+  case 127: { // pages of the zero extent behind compat-mode regions (0: none - sharded zero pages through ROCr; read-only)
+    GpuContext *ctx = KvAllocator::gpu();
+    size_t pages = 0;
+    return ctx && options().zero_backfill.load() && ctx->zero_extent(KvAllocator::page_size(), &pages) ? (int64_t)pages : 0;
+  }
   case 125: return stats().pages_scrubbed;    // pages zeroed on their way back (read-only; reset with the stats)
   case 126: return stats().pages_prescrubbed; // pages a map call handed out without launching a fill for them
   case 124: { // releases of pieces the pool did not know (must stay 0; read-only)

@@ -414,6 +414,12 @@ public:
     if (map(bo, scratch_va_, page_bytes, 0) != 0) return false;
     return clear(scratch_va_, page_bytes) == 0;
   }
+  // "Drop whatever is mapped in [va, va+size) and map this range of `bo` there": alias -> page and page -> alias of the
+  // compat mode's zero extent in ONE ioctl each way, for a whole run of slots (AMDGPU_VA_OP_REPLACE; mappings that
+  // straddle the range are split by the kernel, which is what refresh_mappings_of() is for).
+  int replace(void *bo, void *va, size_t size, uint64_t offset) {
+    return api_.bo_va_op(bo, offset, size, reinterpret_cast<uint64_t>(va), 0, kVaOpReplace);
+  }
   bool can_clear() const { return api_.bo_va_op_raw != nullptr && dev_ != nullptr; }
   int clear(void *va, size_t size) { return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpClear); }
 
@@ -455,7 +461,7 @@ private:
     return r;
   }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
-  static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR
+  static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3, kVaOpReplace = 4; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR / _REPLACE
   struct Api {
     int (*device_initialize)(int, uint32_t *, uint32_t *, void **) = nullptr;
     int (*device_deinitialize)(void *) = nullptr;

@@ -248,6 +248,22 @@ inline bool vmm_try_release(phys_handle_t h) {
   if (vmm_uses_rocr()) return hsa_amd_vmem_handle_release(as_hsa(h)) == HSA_STATUS_SUCCESS;
   return hipMemRelease(as_hip(h)) == hipSuccess;
 }
+// Set by every unmap below, cleared by GpuContext::tlb_shootdown(): "a translation that was valid has been removed and
+// the GPU TLBs have not been invalidated since". While it is set, nothing may be mapped-and-touched, and no physical
+// page may go back to the driver, without an invalidation first: the VMM calls (HIP's, ROCr's and DRM's alike) leave
+// the old translation in the TLBs, and a later map at the same VA would be shadowed by it.
+inline std::atomic<bool> &tlb_stale() {
+  static std::atomic<bool> v{false};
+  return v;
+}
+// `h`: the handle mapped at `va`, when the caller knows it (needed to undo a direct DRM mapping; 0 = an alias or
+// a range, which are always ROCr's / HIP's).
+// The flag is raised AFTER the driver call (and before it, for good measure): an invalidation that starts between
+// "flag set" and "translation removed" clears the flag without covering this unmap.
+struct StaleAfter {
+  StaleAfter() { tlb_stale().store(true); }
+  ~StaleAfter() { tlb_stale().store(true); }
+};
 // The DRM buffer object behind a handle and the page of it the handle names (DrmVm::resolve); nullptr: not a direct buffer.
 inline void *vmm_direct_bo(phys_handle_t h, unsigned *piece = nullptr, unsigned *pages = nullptr) {
   unsigned p = 0;
@@ -267,6 +283,16 @@ inline void vmm_map_pieces(void *va, size_t piece_bytes, size_t count, phys_hand
   if (!bo) throw GpuError("vmm_map_pieces: not a direct DRM buffer");
   const int r = DrmVm::instance().map(bo, va, count * piece_bytes, static_cast<uint64_t>(piece) * piece_bytes);
   if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA map failed: ") + strerror(r < 0 ? -r : r));
+}
+// The same over slots that currently show something else (compat mode: aliases of the zero extent): whatever is mapped in
+// the range is dropped or split and the pieces take its place, in ONE ioctl (AMDGPU_VA_OP_REPLACE).
+inline void vmm_replace_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first) {
+  StaleAfter mark; // live translations are replaced
+  unsigned piece = 0;
+  void *bo = vmm_direct_bo(h_first, &piece);
+  if (!bo) throw GpuError("vmm_replace_pieces: not a direct DRM buffer");
+  const int r = DrmVm::instance().replace(bo, va, count * piece_bytes, static_cast<uint64_t>(piece) * piece_bytes);
+  if (r != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace failed: ") + strerror(r < 0 ? -r : r));
 }
 // Returns whether the mapping still needs vmm_set_access (a DRM mapping is made readable+writable in the same ioctl).
 inline bool vmm_map(void *va, size_t size, phys_handle_t h) {
@@ -311,22 +337,6 @@ inline bool vmm_try_set_access(void *va, size_t size, int dev) {
   const auto acc = make_rw_access(dev);
   return hipMemSetAccess(va, size, &acc, 1) == hipSuccess;
 }
-// Set by every unmap below, cleared by GpuContext::tlb_shootdown(): "a translation that was valid has been removed and
-// the GPU TLBs have not been invalidated since". While it is set, nothing may be mapped-and-touched, and no physical
-// page may go back to the driver, without an invalidation first: the VMM calls (HIP's, ROCr's and DRM's alike) leave
-// the old translation in the TLBs, and a later map at the same VA would be shadowed by it.
-inline std::atomic<bool> &tlb_stale() {
-  static std::atomic<bool> v{false};
-  return v;
-}
-// `h`: the handle mapped at `va`, when the caller knows it (needed to undo a direct DRM mapping; 0 = an alias or
-// a range, which are always ROCr's / HIP's).
-// The flag is raised AFTER the driver call (and before it, for good measure): an invalidation that starts between
-// "flag set" and "translation removed" clears the flag without covering this unmap.
-struct StaleAfter {
-  StaleAfter() { tlb_stale().store(true); }
-  ~StaleAfter() { tlb_stale().store(true); }
-};
 inline void vmm_unmap(void *va, size_t size, phys_handle_t h = 0) {
   StaleAfter mark;
   if (void *bo = h ? vmm_direct_bo(h) : nullptr) {

@@ -114,6 +114,11 @@ GpuContext::~GpuContext() {
   if (scrub_stream_) (void)hipStreamSynchronize(scrub_stream_); // no fill may be running on an alias that is about to go
   extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
   extent_pools_[1].clear();
+  for (auto &kv : zero_extents_) {
+    (void)DrmVm::instance().clear(reinterpret_cast<void *>(kv.second.alias), kv.second.pages * kv.first);
+    (void)DrmVm::instance().forget(kv.second.h);
+  }
+  zero_extents_.clear();
   for (auto &a : arenas_) (void)hipMemAddressFree(a.base, a.size);
   arenas_.clear();
   if (scrub_stream_) (void)hipStreamDestroy(scrub_stream_);
@@ -333,6 +338,40 @@ void GpuContext::wait_scrub(uint64_t ticket) {
   while (cur < covered && !scrub_done_.compare_exchange_weak(cur, covered)) {
   }
   harvest();
+}
+
+phys_handle_t GpuContext::zero_extent(size_t page_bytes, size_t *pages) {
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = zero_extents_.find(page_bytes);
+  if (it != zero_extents_.end()) {
+    *pages = it->second.pages;
+    return it->second.h;
+  }
+  if (vmm_backend() != kVmmDrm || !DrmVm::instance().kfd_ready() || !DrmVm::instance().can_clear()) return 0;
+  // 64 pages (128 MiB of zeros for 2 MiB pages: 0.04 % of the HBM), never more than 256 MiB
+  const size_t n = std::max<size_t>(1, std::min<size_t>(kMaxExtentPages, (256u << 20) / page_bytes));
+  phys_handle_t h = 0;
+  uint64_t alias = 0;
+  try {
+    h = DrmVm::instance().create(n * page_bytes, (unsigned)n);
+    void *bo = DrmVm::instance().find(h);
+    alias = alias_alloc(n * page_bytes);
+    if (!bo || !alias || DrmVm::instance().map(bo, reinterpret_cast<void *>(alias), n * page_bytes, 0) != 0) throw GpuError("mapping the zero extent failed");
+    std::vector<void *> ptrs;
+    for (size_t i = 0; i < n; ++i) ptrs.push_back(reinterpret_cast<void *>(alias + i * page_bytes));
+    bind();
+    zero_fill(ptrs.data(), ptrs.size(), page_bytes, stream_); // what the driver hands out is zero today; not a documented guarantee
+    HIP_CHECK(hipStreamSynchronize(stream_));
+  } catch (const std::exception &e) {
+    KVC_LOG(LOG_WARNING, "no zero extent (%s): compat mode aliases sharded zero pages through ROCr", e.what());
+    if (alias) alias_free(alias, n * page_bytes);
+    if (h) (void)DrmVm::instance().forget(h);
+    (void)hipGetLastError();
+    return 0;
+  }
+  zero_extents_[page_bytes] = ZeroExtent{h, n, alias};
+  *pages = n;
+  return h;
 }
 
 uint64_t GpuContext::alias_alloc(size_t bytes) {
@@ -1180,6 +1219,35 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
 // the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
 void KvAllocator::backfill_all(KvRegion &r) {
+  // drm backend: one buffer of zeros, a whole group of slots aliased per ioctl, no per-slot object anywhere (§4.2):
+  // 2 304 ioctls for the 147 k slots of a 288 GiB reservation instead of 147 k map + set_access pairs.
+  if (env_bool("KVCACHED_ZERO_EXTENT", true)) {
+    size_t zp = 0;
+    if (const phys_handle_t zh = ctx_->zero_extent(r.page_size, &zp)) {
+      void *zbo = DrmVm::instance().find(zh);
+      size_t done = 0;
+      try {
+        for (size_t i = 0; i < r.num_slots(); ++i)
+          if (vmm_hip_registered()) register_slot(r, i); // compat promises zeros to ANY access, hipMemcpy included
+        for (; done < r.num_slots(); done += zp) {
+          const size_t k = std::min(zp, r.num_slots() - done);
+          if (DrmVm::instance().map(zbo, r.base + done * r.page_size, k * r.page_size, 0) != 0)
+            throw GpuError("aliasing the zero extent failed");
+        }
+      } catch (...) {
+        if (done) {
+          StaleAfter mark;
+          (void)DrmVm::instance().clear(r.base, std::min(done, r.num_slots()) * r.page_size);
+        }
+        throw;
+      }
+      r.zx = true;
+      r.zx_handle = zh;
+      r.zx_pages = zp;
+      r.backfilled = true;
+      return; // invalid -> valid: nothing to invalidate; the extent was filled when it was made
+    }
+  }
   r.fanout = (size_t)std::max<int64_t>(1, options().zero_alias_fanout.load());
   const size_t n_zero = (r.num_slots() + r.fanout - 1) / r.fanout;
   r.zero.assign(n_zero, phys_handle_t{});
@@ -1248,6 +1316,10 @@ void KvAllocator::register_slot(KvRegion &r, size_t slot) {
 // (hipMemAddressFree and hipMemRelease expect that). Everything of ours inside a registered unit - pages, zero aliases -
 // is unmapped first; then a stand-in of the unit's size is mapped through ROCr for HIP's unmap to remove.
 void KvAllocator::unregister_slots(KvRegion &r) {
+  if (r.zx) { // pages and zero aliases alike are DRM mappings of ours: one ranged CLEAR drops them all
+    StaleAfter mark;
+    if (DrmVm::instance().clear(r.base, r.size) != 0) KVC_LOG(LOG_ERROR, "dropping the mappings of %s failed", r.name.c_str());
+  }
   hsa_amd_vmem_alloc_handle_t standin[2] = {{}, {}}; // [0] one slot, [1] one group
   bool have_standin[2] = {false, false};
   size_t failures = 0;
@@ -1261,6 +1333,7 @@ void KvAllocator::unregister_slots(KvRegion &r) {
     char *va = r.base + first * r.page_size;
     for (size_t i = first; i < first + count; ++i) {
       char *sva = r.base + i * r.page_size;
+      if (r.zx) continue; // (cleared above)
       if (r.mapped[i]) {
         if (!vmm_try_unmap(sva, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
       } else if (r.backfilled) {
@@ -1584,7 +1657,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   uint64_t need_epoch = 0;
   for (auto &s : slots) need_epoch = std::max(need_epoch, s.region->stale_epoch[s.index]);
   const bool blanket = options().map_waits_for_all_flushes.load() != 0;
+  void *zx_dirty = nullptr; // compat mode, zero extent: its group mappings were split by this batch's REPLACEs (§4.8's hazard)
   auto flush_for_batch = [&]() {
+    if (zx_dirty) { // the remainders of the zero extent's mappings are rewritten before the invalidation that covers them
+      if (!DrmVm::instance().refresh_mappings_of(zx_dirty, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of the zero extent failed");
+      tlb_stale().store(true);
+      need_epoch = ctx->next_flush_epoch();
+      zx_dirty = nullptr;
+    }
     if (blanket || always_flush)
       ctx->ensure_flushed();
     else
@@ -1654,8 +1734,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
       if (vmm_hip_registered() && !r.registered[s.index]) register_slot(r, s.index); // once per slot
-      if (r.backfilled) {
-        vmm_unmap(va, ps);
+      if (r.backfilled && !(chunked && r.zx)) {
+        if (r.zx) {
+          StaleAfter mark;
+          if (DrmVm::instance().clear(va, ps) != 0) throw GpuError("dropping a zero alias failed");
+          zx_dirty = DrmVm::instance().find(r.zx_handle);
+        } else {
+          vmm_unmap(va, ps);
+        }
         dirty_tlb = true; // the alias's translation is live
         need_epoch = ctx->next_flush_epoch();
       }
@@ -1666,7 +1752,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (imported) {
         import_index = next_import;
         ph = Phys{(*imported)[next_import++], 0};
-      } else if (chunked && !r.backfilled) {
+      } else if (chunked && (!r.backfilled || r.zx)) {
         fresh.push_back(s); // backed below, run by run: adjacent slots share one ioctl
         stats().t_unmap_alias += t1 - t0;
         continue;
@@ -1686,7 +1772,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
         needs_access = vmm_map(va, ps, h);
       } catch (...) {
         if (!imported) pool->release(ph);
-        if (r.backfilled && vmm_try_map(va, ps, r.zero_of(s.index))) (void)vmm_try_set_access(va, ps, ctx->dev());
+        if (r.zx)
+          (void)DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), va, ps, (s.index % r.zx_pages) * ps);
+        else if (r.backfilled && vmm_try_map(va, ps, r.zero_of(s.index)))
+          (void)vmm_try_set_access(va, ps, ctx->dev());
         throw;
       }
       int64_t t3 = now_ns();
@@ -1747,7 +1836,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           const int64_t t2 = now_ns();
           char *va = r.base + fresh[i].index * ps;
           try {
-            vmm_map_pieces(va, ps, n, got[0].h);
+            if (r.zx) { // the slots show pages of the zero extent: pages take their place in the same ioctl
+              vmm_replace_pieces(va, ps, n, got[0].h);
+              zx_dirty = DrmVm::instance().find(r.zx_handle);
+              dirty_tlb = true;
+              need_epoch = ctx->next_flush_epoch();
+            } else {
+              vmm_map_pieces(va, ps, n, got[0].h);
+            }
           } catch (...) {
             pool->release_batch(got.data(), n);
             throw;
@@ -1789,7 +1885,12 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     for (auto it = done.rbegin(); it != done.rend(); ++it) {
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
-      (void)vmm_try_unmap(va, ps, r.handle[it->index]);
+      if (r.zx) { // back to its page of the zero extent, the page dropped in the same ioctl
+        StaleAfter mark;
+        (void)DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), va, ps, (it->index % r.zx_pages) * ps);
+      } else {
+        (void)vmm_try_unmap(va, ps, r.handle[it->index]);
+      }
       if (vmm_extent_pages(r.handle[it->index]) > 1)
         if (void *bo = vmm_direct_bo(r.handle[it->index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
       if (r.mapped[it->index] == 1)
@@ -1797,7 +1898,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       else
         (void)vmm_try_release(r.handle[it->index]);
       r.mapped[it->index] = 0;
-      if (r.backfilled && vmm_try_map(va, ps, r.zero_of(it->index))) (void)vmm_try_set_access(va, ps, ctx->dev());
+      if (r.backfilled && !r.zx && vmm_try_map(va, ps, r.zero_of(it->index))) (void)vmm_try_set_access(va, ps, ctx->dev());
     }
     (void)hipGetLastError();
     try {
@@ -1853,6 +1954,38 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
   std::vector<uint8_t> cleared(slots.size(), 0);
+  { // compat mode, zero extent: a run of adjacent slots goes back to showing zeros with ONE ioctl - the pages of the
+    // zero extent replace whatever is mapped there (runs end at the extent's group boundaries: slot i shows page i % Z)
+    std::vector<uint32_t> zorder;
+    for (uint32_t i = 0; i < slots.size(); ++i) {
+      const KvRegion &r = *slots[i].region;
+      const uint8_t m = r.mapped[slots[i].index];
+      if (r.zx && (m == 1 || m == 2)) zorder.push_back(i);
+    }
+    std::sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
+      return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
+    });
+    for (size_t i = 0; i < zorder.size();) {
+      KvRegion &r = *slots[zorder[i]].region;
+      const size_t first = slots[zorder[i]].index;
+      size_t j = i + 1, last = first;
+      while (j < zorder.size() && slots[zorder[j]].region == &r &&
+             (slots[zorder[j]].index == last || (slots[zorder[j]].index == last + 1 && (last + 1) % r.zx_pages != 0))) {
+        last = slots[zorder[j]].index; // (a slot listed twice stays inside its run: logged as "not mapped" below)
+        ++j;
+      }
+      const int64_t t0 = now_ns();
+      {
+        StaleAfter mark;
+        const int rc = DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), r.base + first * ps, (last - first + 1) * ps,
+                                                 (first % r.zx_pages) * ps);
+        if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the zero extent) failed: ") + strerror(rc < 0 ? -rc : rc));
+      }
+      stats().t_unmap += now_ns() - t0;
+      for (size_t k = i; k < j; ++k) cleared[zorder[k]] = 1;
+      i = j;
+    }
+  }
   size_t max_clear = (size_t)options().clear_run_slots.load();
   if (max_clear >= 2 && xpool->multi_page()) max_clear = std::max<size_t>(max_clear, xpool->max_extent_pages()); // a whole extent in one go
   if (max_clear >= 2 && slots.size() >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
@@ -1908,7 +2041,9 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     gone.emplace_back(&r, s.index);
     ++u.n;
     if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
-    if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
+    if (r.zx) {
+      u.any_backfilled = true; // (its zeros are back already: REPLACE above)
+    } else if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();
       vmm_map(va, ps, r.zero_of(s.index));

@@ -107,6 +107,9 @@ public:
   // VA for alias mappings (never handed to anybody): carved from arenas reserved 64 GiB at a time
   uint64_t alias_alloc(size_t bytes);
   void alias_free(uint64_t va, size_t bytes);
+  // The buffer of zeros behind the unbacked slots of compat-mode regions (drm backend): created and filled on first use,
+  // `*pages` pages of `page_bytes`; 0 if it cannot be had (the caller aliases sharded zero pages through ROCr instead).
+  phys_handle_t zero_extent(size_t page_bytes, size_t *pages);
   // block id <-> token index glue (index_kernels.hip); ids are HOST arrays, everything else device memory
   void expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s);
   void alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
@@ -175,6 +178,12 @@ private:
   std::mutex arena_mu_;
   std::vector<Arena> arenas_;
   std::map<size_t, std::vector<uint64_t>> alias_free_; // by size: extents come in a handful of sizes
+  struct ZeroExtent {
+    phys_handle_t h;
+    size_t pages;
+    uint64_t alias;
+  };
+  std::map<size_t, ZeroExtent> zero_extents_; // by page size
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;
   // unique_block_ids scratch (grow-only; bitmap all-zero and header reset between calls)
@@ -198,6 +207,12 @@ struct KvRegion {
   std::vector<phys_handle_t> zero;     // zero pages of this region; slot i aliases zero[i / fanout]
   size_t fanout = 1;
   phys_handle_t zero_of(size_t slot) const { return zero[slot / fanout]; }
+  // drm backend ("zero extent"): unbacked slots alias the pages of ONE multi-page buffer of zeros that the GPU context
+  // owns - slot i shows its page i % zx_pages - mapped through DRM a whole group of zx_pages slots per ioctl; a run of
+  // slots goes alias -> pages and pages -> alias with one REPLACE each
+  bool zx = false;
+  phys_handle_t zx_handle = 0;
+  size_t zx_pages = 0;
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
   std::vector<uint64_t> stale_epoch;   // per slot: the TLB invalidation (GpuContext::next_flush_epoch) that covers its last unmap

@@ -197,13 +197,21 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
         k = k_tensors[0]
         tpp = PAGE_SIZE // (k.stride()[0] * dtype.itemsize)   # tokens per physical page
 
-        # without alloc(): token 1 of pages 1..60 (page 0 holds the null block and is backed)
-        for i in range(1, 61):
+        # without alloc(): token 1 of unbacked pages (page 0 holds the null block and is backed). What the reference's script
+        # demonstrates - writes to memory nobody allocated land on shared zero memory and overwrite each other - holds here
+        # too, with a different period: the reference aliases every unbacked page to ONE zero page; the drm backend shows
+        # page i % z of one zero extent behind slot i (z = 64), the sharded fallback one zero page per 256 slots.
+        from kvcached_amd import capi
+        z = capi.get_option(capi.OPT_ZERO_EXTENT_PAGES) or 1
+        n_slots = k.numel() * dtype.itemsize // PAGE_SIZE
+        pages = [p for p in range(1, min(n_slots, 1 + 3 * z))][:max(60, 2 * z + 8)]
+        for i in pages:
             k[1 + i * tpp] = torch.full((heads, dim), float(i), dtype=dtype, device=DEV)
         torch.cuda.synchronize()
-        back = [float(k[1 + i * tpp][0][0]) for i in range(1, 61)]
-        assert sum(1 for i, b in enumerate(back, start=1) if b == float(i)) < 60, "aliasing not observed"
-        assert len(set(back)) == 1                      # they all see the last write
+        back = {i: float(k[1 + i * tpp][0][0]) for i in pages}
+        assert sum(1 for i, b in back.items() if b == float(i)) < len(pages), "aliasing not observed"
+        for i in pages:                                  # every slot sees the LAST write to its zero page
+            assert back[i] == float(max(j for j in pages if j % z == i % z)), (i, z, back[i])
 
         # with alloc(): unique physical pages
         blocks_per_page = PAGE_SIZE // (page_tokens * cell)
