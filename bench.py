@@ -51,9 +51,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--mode", choices=["lazy", "compat"], default="lazy",
-                    help="lazy (library default on ROCm): unbacked VA stays unmapped; compat: unbacked VA aliases "
-                         "(sharded) zero pages like the reference")
+    ap.add_argument("--mode", choices=["lazy", "compat"], default="compat",
+                    help="compat (library default, the reference's semantics): unbacked VA shows zeros (the pages of one zero "
+                         "extent); lazy (KVCACHED_ZERO_BACKFILL=false): unbacked VA stays unmapped, a stray access faults")
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -464,7 +464,7 @@ def main():
 
     if args.growth_burst_only:   # child of the N=1 run: the first GPU work of a fresh process
         os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_bench_gb_{os.getpid()}")
-        r1 = measure(capi, device, 24, 0, "lazy", None, burst=True, prefault=False, backend=args.backend)
+        r1 = measure(capi, device, 24, 0, args.mode, None, burst=True, prefault=False, backend=args.backend)
         s = summarize(r1, 24)
         out = {k: (round(s[k], 3) if isinstance(s[k], float) else s[k]) for k in
                ("GBps", "p50_map_batch_ms", "map_us_per_page", "handles_created", "driver_us_per_page")}
@@ -479,7 +479,7 @@ def main():
     first_touch = None
     if world == 1 and not rehearsal and not args.no_variants and not use_dist_requested():
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--growth-burst-only", "--backend", args.backend],
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--growth-burst-only", "--backend", args.backend, "--mode", args.mode],
                                  capture_output=True, text=True, timeout=300)
             js = [l for l in out.stdout.splitlines() if l.startswith("{")]
             first_touch = json.loads(js[-1]) if out.returncode == 0 and js else {"error": (out.stderr or out.stdout)[-300:]}
@@ -563,7 +563,7 @@ def main():
             if not args.no_variants:
                 variants = {}
                 # name -> (mode, pool cap MB, compound layers, burst, prefault, backend, page, extra environment, steps)
-                V = lambda mode="lazy", pool=None, comp=0, burst=False, pre=True, be=None, page=PAGE, env=None, n=24: \
+                V = lambda mode=args.mode, pool=None, comp=0, burst=False, pre=True, be=None, page=PAGE, env=None, n=24: \
                     (mode, pool, comp, burst, pre, be or args.backend, page, env or {}, n)   # noqa: E731
                 table = {
                     "one_buffer_per_page_round1_default": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "1"}),
@@ -571,11 +571,13 @@ def main():
                     "extents_up_to_64_pages": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "64"}),
                     "unmap_waits_for_its_own_tlb_invalidation": V(env={"KVCACHED_ASYNC_SHOOTDOWN": "false"}),
                     "tlb_flush_through_hipMalloc_instead_of_kfd": V(env={"KVCACHED_KFD_TLB_FLUSH": "false"}),
-                    "compat_zero_extent": V(mode="compat"),
-                    "compat_zero_backfill_sharded": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false"}),
+                    "lazy_mode_opt_in": V(mode="lazy"),
+                    "lazy_mode_map_waits_for_all_invalidations": V(mode="lazy", env={"KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES": "true"}),
+                    "lazy_mode_fill_in_the_map_call": V(mode="lazy", env={"KVCACHED_SCRUB_ON_RELEASE": "false"}),
+                    "compat_sharded_zero_pages_through_rocr_round1": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false"}),
                     "hybrid_backend_same_cycle": V(be="hybrid"),
                     "hip_backend_same_cycle": V(be="hip"),
-                    "hip_backend_compat_zero_backfill_sharded": V(mode="compat", be="hip", n=8),
+                    "hip_backend_lazy": V(mode="lazy", be="hip"),
                     "fresh_va_window_warm_process": V(pre=False),
                     "growth_burst_24x2GiB_nothing_unmapped": V(burst=True, pre=False),   # growth = fresh VA, fresh handles
                     "growth_burst_one_buffer_per_page": V(burst=True, pre=False, env={"KVCACHED_PHYS_CHUNK_PAGES": "1"}),
@@ -608,7 +610,8 @@ def main():
                                 os.environ[k] = v
                 line["variants"] = variants
                 # the reference's semantics (unbacked VA reads as zeros) next to the headline, not only among the variants
-                line["compat_mode_GBps"] = variants.get("compat_zero_extent", {}).get("GBps")
+                line["lazy_mode_GBps"] = variants.get("lazy_mode_opt_in", {}).get("GBps")
+                line["lazy_mode_p50_map_batch_ms"] = variants.get("lazy_mode_opt_in", {}).get("p50_map_batch_ms")
                 try:
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)
                 except Exception as e:

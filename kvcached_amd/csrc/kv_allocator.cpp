@@ -947,10 +947,13 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
     g_page_size = page_size;
   }
   // environment knobs, read once per init
-  // Default OFF on ROCm: with every unbacked slot aliased, each hipMemCreate costs O(mappings in the
-  // process) — ~2 ms at the 147k slots of a 288 GiB reservation. Opt in with
-  // KVCACHED_ZERO_BACKFILL=true for the reference's "stray reads return zeros" semantics.
-  options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", false) ? 1 : 0;
+  // Default ON since round 2, as in the reference (csrc/ftensor.cpp:160-176: unbacked VA reads as zeros instead of
+  // faulting). Round 1 had it off: with per-slot aliases through ROCr every creation cost O(mappings in the process) and
+  // the cycle ran at 160 GB/s; with the drm backend's zero extent (backfill_all) it is 1.5 TB/s and start-up is 2 304
+  // ioctls for a 288 GiB reservation. KVCACHED_ZERO_BACKFILL=false ("lazy": unbacked VA stays unmapped, a stray access
+  // FAULTS) is the opt-in for engines that never touch a block they do not own: 4.3 TB/s, no invalidation on the
+  // allocation path.
+  options().zero_backfill = env_bool("KVCACHED_ZERO_BACKFILL", true) ? 1 : 0;
   options().zero_fill = env_bool("KVCACHED_ZERO_FILL", true) ? 1 : 0;
   options().pool_bytes = env_i64("KVCACHED_PHYS_POOL_MB", 16384) << 20;
   options().tlb_shootdown = env_bool("KVCACHED_TLB_SHOOTDOWN", true) ? 1 : 0;
@@ -2042,7 +2045,10 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     ++u.n;
     if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
     if (r.zx) {
-      u.any_backfilled = true; // (its zeros are back already: REPLACE above)
+      // Its zeros are back already (REPLACE above); the invalidation happens inside this call, like for any compat region:
+      // "unbacked VA reads as zeros" holds from the moment unmap returns (an asynchronous invalidation would let a read
+      // that follows at once still see the old page - observable, so not done).
+      u.any_backfilled = true;
     } else if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();

@@ -183,8 +183,8 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
     from kvcached_amd.utils import PAGE_SIZE
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
     monkeypatch.setattr(si, "_contiguous_layout", False)
-    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true")   # the reference's zero-page semantics are opt-in here
-    tokens, page_tokens, heads, dim, layers = 65536, 16, 8, 64, 2
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true")   # (the default since round 2)
+    tokens, page_tokens, heads, dim, layers = 262144, 16, 8, 64, 2   # 128 pages of 2 MiB per K tensor: two periods of the zero extent
     dtype = torch.float16
     si.init_kvcached(async_sched=False)
     try:
@@ -376,10 +376,12 @@ def test_golden_trace_with_async_unmap(monkeypatch):
     from kvcached_amd import capi
     case = load("manager_large.json")["cases"][2]
     os.environ["KVCACHED_ASYNC_UNMAP"] = "true"
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "false"   # queued unmaps are a lazy-mode feature (compat promises zeros behind an unmap at once)
     try:
         ad = _gpu_adapter(case["config"])
     finally:
         os.environ.pop("KVCACHED_ASYNC_UNMAP", None)
+        os.environ.pop("KVCACHED_ZERO_BACKFILL", None)
     try:
         assert capi.get_option(capi.OPT_ASYNC_UNMAP) == 1
         init = {"s": ad.snapshot(), "e": ad.drain_events()}
@@ -403,6 +405,8 @@ def test_pool_eviction_is_left_to_the_housekeeping_thread(monkeypatch):
     free() path (hipMemRelease of a used handle is 40-50 us: 200 ms for a 4096-slot free) but by the 10 Hz
     housekeeping; without one (plain C-ABI use) the release stays immediate."""
     monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", "1")   # page-granular counts
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "false")  # lazy mode: free() is a few ms here, well inside one housekeeping tick
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "0")    # exact counts: no pre-created reserve
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
@@ -440,9 +444,11 @@ def test_pool_eviction_is_left_to_the_housekeeping_thread(monkeypatch):
 def test_unmap_leaves_its_tlb_invalidation_to_the_watcher_thread(monkeypatch):
     """With an allocator watcher thread (every engine has one: it runs with the prealloc thread), free() does not pay
     the 0.3-0.4 ms KFD round trip of the TLB invalidation: the unmap batch marks it owed and the watcher's next tick
-    performs it - or the next map batch does, whichever comes first. Pages stay private either way."""
+    performs it - or the next map batch does, whichever comes first. Pages stay private either way. (Lazy mode: a compat
+    region promises zeros behind an unmap at once and invalidates inside the call.)"""
     import kvcached_amd.kv_cache_manager as kcm
     from kvcached_amd import capi, vmm_ops
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "false")
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
     monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)
     vmm_ops.init_kvcached(DEV, T.PAGE, False)
