@@ -237,7 +237,8 @@ int64_t kvc_get_region_bases(int64_t group_id, void **out, int64_t cap);
  * allocators; replaces the torch/Triton glue of the reference's ElasticTokenToKVPoolAllocator and
  * ElasticPagedTokenToKVPoolAllocator (kvcached/integration/sglang/patches.py:100-117,186-276).
  * `block_ids` / `new_block_ids` are HOST arrays (what alloc() returned); every other pointer is device
- * memory (int64). Asynchronous on `stream` (NULL = the library's stream) unless stated otherwise.
+ * memory (int64). Asynchronous on `stream` unless stated otherwise; NULL = the device's default (null) stream, i.e. what
+ * torch.cuda.current_stream() is unless the caller switched streams - these kernels consume and produce the caller's tensors.
  *
  * kvc_expand_block_ids      out[i*tpb + j] = block_ids[i]*tpb + j             (patches.py:188-197; tpb = 1: :100-102)
  * kvc_alloc_extend_indices  request r grows from prefix_lens[r] to seq_lens[r] tokens: tokens that still fit its

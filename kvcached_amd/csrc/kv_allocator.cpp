@@ -442,7 +442,8 @@ struct StagedIds {
 } // namespace
 
 void GpuContext::expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s) {
-  if (!s) s = stream_;
+  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
+  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
   for (size_t i = 0; i < n; i += kMaxIdsPerLaunch) {
     const size_t k = std::min<size_t>(kMaxIdsPerLaunch, n - i);
     HIP_CHECK(launch_expand_block_ids(ids + i, nullptr, k, tpb, out + i * (size_t)tpb, s));
@@ -453,7 +454,8 @@ void GpuContext::expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int
 void GpuContext::alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
                                       const int64_t *ids, size_t n_ids, int64_t tpb, int64_t *out, size_t out_len,
                                       hipStream_t s) {
-  if (!s) s = stream_;
+  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
+  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
   if (n_ids <= (size_t)kMaxIdsPerLaunch) {
     HIP_CHECK(launch_alloc_extend(ids, nullptr, n_ids, pre_lens, seq_lens, last_loc, bs, tpb, out, out_len, s));
   } else {
@@ -465,7 +467,8 @@ void GpuContext::alloc_extend_indices(const int64_t *pre_lens, const int64_t *se
 
 void GpuContext::alloc_decode_indices(const int64_t *seq_lens, const int64_t *last_loc, size_t bs, const int64_t *ids,
                                       size_t n_ids, int64_t tpb, int64_t *out, hipStream_t s) {
-  if (!s) s = stream_;
+  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
+  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
   if (n_ids <= (size_t)kMaxIdsPerLaunch) {
     HIP_CHECK(launch_alloc_decode(ids, nullptr, n_ids, seq_lens, last_loc, bs, tpb, out, s));
   } else {
@@ -483,7 +486,8 @@ void GpuContext::reset_unique_scratch() {
 
 int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, int64_t *out_host,
                                      size_t cap, hipStream_t s) {
-  if (!s) s = stream_;
+  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
+  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
   if (tpb <= 0 || n_blocks <= 0) throw InvalidError("tokens_per_block and num_blocks must be positive");
   std::lock_guard<std::mutex> g(uniq_mu_);
   const size_t words = ((size_t)n_blocks + 31) / 32;
@@ -1963,7 +1967,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     for (uint32_t i = 0; i < slots.size(); ++i) {
       const KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if (r.zx && (m == 1 || m == 2)) zorder.push_back(i);
+      if (r.zx && (m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])) zorder.push_back(i); // (a page ROCr mapped is ROCr's to unmap)
     }
     std::sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
       return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
@@ -2049,6 +2053,9 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       // "unbacked VA reads as zeros" holds from the moment unmap returns (an asynchronous invalidation would let a read
       // that follows at once still see the old page - observable, so not done).
       u.any_backfilled = true;
+      if (!cleared[si] && // unmapped through ROCr just now (a page imported that way): its page of the zero extent goes back
+          DrmVm::instance().map(DrmVm::instance().find(r.zx_handle), va, ps, (s.index % r.zx_pages) * ps) != 0)
+        KVC_LOG(LOG_ERROR, "putting slot %zu back on the zero extent failed", s.index);
     } else if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();

@@ -923,6 +923,111 @@ def test_export_import_same_process(vmm):
     assert ops.unmap_from_kv_tensors([PAGE], 0)
 
 
+@pytest.mark.parametrize("mode", ["lazy", "compat"])
+def test_import_falls_back_to_rocr_when_the_direct_import_is_refused(vmm, monkeypatch, mode):
+    """A peer's page is taken straight into KFD + DRM (AMDKFD_IOC_IMPORT_DMABUF, one GEM_VA map). A buffer that lives on
+    ANOTHER GPU may be refused by that shortcut; ROCr's import - which sets up peer access for the local agent - is the
+    fallback. One GPU cannot show the cross-GPU case itself: a hook makes the direct import fail, and the
+    page must arrive through ROCr all the same, be shared byte for byte, and leave no imported handle behind."""
+    ops, capi = vmm["ops"], vmm["capi"]
+    monkeypatch.setenv("KVCACHED_EXPORTABLE_HANDLES", "1")
+    monkeypatch.setenv("KVCACHED_TEST_FAIL_KFD_IMPORT", "1")
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true" if mode == "compat" else "false")
+    ops.init_kvcached(DEV, PAGE, False)
+    a = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 2, 0, False)
+    b = ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 2, 1, False)         # group 1 = the "peer"
+    epp = PAGE // 2
+    for rnd in range(3):
+        assert ops.map_to_kv_tensors([PAGE, 3 * PAGE], 0)
+        fds = capi.export_mapped_slots([PAGE, 3 * PAGE], 0)
+        assert len(fds) == 4
+        capi.map_imported_slots([PAGE, 3 * PAGE], fds, 1)
+        for fd in fds:
+            os.close(fd)
+        a[0][epp:epp + 16] = 4321 + rnd
+        a[0][3 * epp:3 * epp + 16] = 77 + rnd
+        torch.cuda.synchronize()
+        assert bool((b[0][epp:epp + 16] == 4321 + rnd).all()) and bool((b[0][3 * epp:3 * epp + 16] == 77 + rnd).all())
+        assert ops.unmap_from_kv_tensors([PAGE, 3 * PAGE], 1)              # the imports are dropped at once
+        if mode == "compat":
+            assert int(torch.count_nonzero(b[0][epp:2 * epp])) == 0           # zeros behind the unmap
+        assert ops.unmap_from_kv_tensors([PAGE, 3 * PAGE], 0)
+    # an import into a slot that is already backed is skipped like a double map - and its handle must not stay imported
+    assert ops.map_to_kv_tensors([PAGE], 0) and ops.map_to_kv_tensors([PAGE], 1)
+    fds = capi.export_mapped_slots([PAGE], 0)
+    capi.map_imported_slots([PAGE], fds, 1)                               # logged "already mapped", nothing consumed
+    for fd in fds:
+        os.close(fd)
+    b[0][epp:epp + 8] = 5
+    a[0][epp:epp + 8] = 6
+    torch.cuda.synchronize()
+    assert bool((b[0][epp:epp + 8] == 5).all())                           # group 1 kept its own page
+    assert ops.unmap_from_kv_tensors([PAGE], 1) and ops.unmap_from_kv_tensors([PAGE], 0)
+    ops.shutdown_kvcached()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: a page of cuda:0 mapped by a process on cuda:1 over xGMI "
+                    "(BASELINE configs[3]); never ran on hardware - the driver's 8-GPU node is the only place it can")
+def test_a_peer_on_another_gpu_maps_rank0_pages():
+    """Cross-GPU shared pool: rank 0 (cuda:0) backs and exports, a peer process on cuda:1 imports and maps."""
+    import multiprocessing as mp
+    import subprocess
+    import sys
+    child = r"""
+import os, sys, socket, array
+sys.path.insert(0, %r)
+import torch
+torch.cuda.set_device(1)
+from kvcached_amd import capi, vmm_ops
+PAGE = 2 << 20
+vmm_ops.init_kvcached("cuda:1", PAGE, False)
+ts = vmm_ops.create_kv_tensors(16 << 20, 2, "cuda:1", 1, 2, 0, False)
+s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM); s.connect(sys.argv[1])
+msg, anc, _, _ = s.recvmsg(16, socket.CMSG_LEN(8 * 4))
+fds = array.array("i"); fds.frombytes(anc[0][2][:8])
+capi.map_imported_slots([PAGE], list(fds), 0)
+epp = PAGE // 2
+print("PEER SEES", int(ts[0][epp + 7]), int(ts[0][ts[0].numel() // 2 + epp + 7]), flush=True)
+ts[0][epp + 9] = 777
+torch.cuda.synchronize()
+s.sendall(b"k")
+s.recv(1)
+vmm_ops.unmap_from_kv_tensors([PAGE]); vmm_ops.shutdown_kvcached()
+"""
+    import socket, array, tempfile
+    from kvcached_amd import capi, vmm_ops
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    try:
+        vmm_ops.init_kvcached(DEV, PAGE, False)
+        ts = vmm_ops.create_kv_tensors(16 * MiB, 2, DEV, 1, 2, 0, False)
+        assert vmm_ops.map_to_kv_tensors([PAGE])
+        epp = PAGE // 2
+        ts[0][epp + 7] = 1001
+        ts[0][ts[0].numel() // 2 + epp + 7] = 1002
+        torch.cuda.synchronize()
+        fds = capi.export_mapped_slots([PAGE], 0)
+        path = os.path.join(tempfile.mkdtemp(), "x.sock")
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(path)
+        srv.listen()
+        p = subprocess.Popen([sys.executable, "-c", child % repo, path], stdout=subprocess.PIPE, text=True)
+        conn, _ = srv.accept()
+        conn.sendmsg([b"fds"], [(socket.SOL_SOCKET, socket.SCM_RIGHTS, array.array("i", fds))])
+        assert conn.recv(1) == b"k"
+        torch.cuda.synchronize()
+        assert int(ts[0][epp + 9]) == 777                                 # the peer's write over xGMI landed in rank 0's page
+        conn.sendall(b"k")
+        out, _ = p.communicate(timeout=120)
+        assert "PEER SEES 1001 1002" in out, out
+        for fd in fds:
+            os.close(fd)
+        assert vmm_ops.unmap_from_kv_tensors([PAGE])
+    finally:
+        os.environ.pop("KVCACHED_EXPORTABLE_HANDLES", None)
+        vmm_ops.shutdown_kvcached()
+
+
 # ------------------------------------------------------------------ shared pool across processes
 def _peer_process(sock_path, ipc, q):
     """The 'peer TP rank': owns its own VA reservation, receives fds over the Unix socket and maps them."""
