@@ -249,7 +249,8 @@ def get_region_bases(group_id: int = 0) -> List[int]:
 
 
 # ---- block ids <-> token slot indices. Device arrays are passed as raw addresses (tensor.data_ptr()),
-# `stream` as the raw hipStream_t (torch.cuda.current_stream().cuda_stream); 0 = the library's own stream.
+# `stream` as the raw hipStream_t (torch.cuda.current_stream().cuda_stream); 0 = the device's default (null) stream, which
+# is what torch's current stream is unless the caller switched.
 def expand_block_ids(block_ids: Sequence[int], tokens_per_block: int, out_ptr: int, stream: int = 0) -> None:
     check(lib.kvc_expand_block_ids(i64_array(block_ids), len(block_ids), tokens_per_block, out_ptr, stream))
 

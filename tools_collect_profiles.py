@@ -11,7 +11,8 @@ ks, kt = newest("gpurun_out/prof_kt/runc/*_kernel_stats.csv"), newest("gpurun_ou
 shutil.copy(ks, f"profiles/{R}_rocprofv3_kernel_stats.csv")
 shutil.copy(newest("gpurun_out/prof_kt/runc/*_domain_stats.csv"), f"profiles/{R}_rocprofv3_domain_stats.csv")
 rows = list(csv.DictReader(open(kt)))
-# the bench's fill launches: a 1024-page batch is filled as 768 + 256 pages (grid = pages x 32 workgroups x 512 threads)
+# the bench's fill launches (grid = pages x 32 workgroups x 512 threads): round 1 filled a 1024-page batch as 768 + 256 pages inside
+# the map call; since round 2 it is ONE 1024-page launch, queued behind the unmap (pages are zeroed on their way back)
 SHAPES = {"12582912": 768, "4194304": 256, "16777216": 1024}
 big = [r for r in rows if "zero_fill" in r["Kernel_Name"] and r["Grid_Size_X"] in SHAPES]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in big]
@@ -27,7 +28,7 @@ per_shape = {}
 for r, us in zip(big, d):
     per_shape.setdefault(SHAPES[r["Grid_Size_X"]], []).append(us)
 out = {"kernel": "kvc::zero_fill_pages_kernel<512,false,true>",
-       "launch_shape": "a 1024-page batch = one launch of 768 pages (hidden behind the last 256 maps) + one of 256; 32 workgroups x 512 threads per 2 MiB page",
+       "launch_shape": "a 1024-page batch = ONE launch (2 GiB), queued on the library's scrub stream when the batch is unmapped; 32 workgroups x 512 threads per 2 MiB page",
        "algorithmic_bytes_per_launch": int(sum(algo) / len(algo)),
        "rocprofv3_kernel_trace": {"launches": len(d), "avg_us": round(sum(d) / len(d), 2), "median_us": round(statistics.median(d), 2),
                                   "min_us": round(min(d), 2), "max_us": round(max(d), 2), "GBps_at_avg": round(sum(algo) / sum(d) / 1e3, 1),
