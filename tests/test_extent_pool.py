@@ -16,8 +16,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def report(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("native") / "extent_pool_check")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-o", exe,
-                           os.path.join(REPO, "tests", "native", "extent_pool_check.cpp")])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+                           os.path.join(REPO, "tests", "native", "extent_pool_check.cpp")],
+                          env={k: v for k, v in os.environ.items() if k != "LD_PRELOAD"})
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}   # (tools_sanitize_cpu.sh preloads clang's runtime: this binary has gcc's)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]   # every REQUIRE in the program is an invariant
     return json.loads(out.stdout)
 

@@ -109,7 +109,9 @@ def test_prealloc_thread_invariants(cpu_ops):
     t0 = time.time()
     while pa.get_num_reserved_pages() < 5 and time.time() - t0 < 5:
         time.sleep(0.005)
-    assert 5 <= pa.get_num_reserved_pages() <= 10
+    # (free_pages fills the reserved list up to MAX_RESERVED (10) while the thread may have a refill of up to MIN_RESERVED (5)
+    # pages in flight - decided before the free, appended after it: the same in the reference, whose list is not capped there)
+    assert 5 <= pa.get_num_reserved_pages() <= 15
     pa.stop_prealloc_thread()   # (a page the thread is moving from the free list to the reserved list is in neither for a moment)
     pa.stop_prealloc_thread()
     assert sorted(pa._page_list(0) + pa._page_list(1) + held[25:]) == list(range(64))
