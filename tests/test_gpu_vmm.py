@@ -106,12 +106,19 @@ def test_map_gives_private_zeroed_pages_even_when_recycled(vmm):
     assert ops.unmap_from_kv_tensors([PAGE, 2 * PAGE, 4 * PAGE])
 
 
-_CONFIGS = [(b, mode, au, ck) for b in ("drm", "hybrid", "hip") for mode in ("lazy", "compat") for au in (0, 1)
-            for ck in ((1, 32) if b == "drm" else (1,)) if not (mode == "compat" and au)]   # async unmap is ignored in compat mode
+_CONFIGS = [(b, mode, au, ck, "") for b in ("drm", "hybrid", "hip") for mode in ("lazy", "compat") for au in (0, 1)
+            for ck in ((1, 64) if b == "drm" else (1,)) if not (mode == "compat" and au)]   # async unmap is ignored in compat mode
+# ... and the default backend with each of round 2's mechanisms switched off in turn (every switch that ships is a
+# correctness surface for stale translations and recycled pages)
+_CONFIGS += [("drm", mode, 0, 64, off) for mode in ("lazy", "compat")
+             for off in ("KVCACHED_SCRUB_ON_RELEASE=false", "KVCACHED_KFD_TLB_FLUSH=false", "KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES=true",
+                         "KVCACHED_ASYNC_SHOOTDOWN=false")]
+_CONFIGS += [("drm", "compat", 0, 64, "KVCACHED_ZERO_EXTENT=false"), ("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true")]
 
 
-@pytest.mark.parametrize("backend,mode,async_unmap,extent_pages", _CONFIGS)
-def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkeypatch, backend, mode, async_unmap, extent_pages):
+@pytest.mark.parametrize("backend,mode,async_unmap,extent_pages,switch", _CONFIGS)
+def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkeypatch, backend, mode, async_unmap, extent_pages,
+                                                                     switch):
     """The stale-translation / recycled-page property over every combination that ships: VMM backend x lazy|compat x
     synchronous|queued unmaps x single-page|run-sized extents. Each round backs a random set of slots (they must read
     zero - never the page's or the slot's previous contents), stamps them, takes a random subset away again (in compat
@@ -121,13 +128,15 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
     monkeypatch.setenv("KVCACHED_VMM_BACKEND", backend)
     monkeypatch.setenv("KVCACHED_ASYNC_UNMAP", "true" if async_unmap else "false")
     monkeypatch.setenv("KVCACHED_PHYS_CHUNK_PAGES", str(extent_pages))
+    if switch:
+        monkeypatch.setenv(*switch.split("="))
     ops, capi, ts = _setup(vmm, layers=2, per_layer=64 * PAGE, backfill=(mode == "compat"), kv=1, unified=False)
     want_backend = {"drm": 3, "hybrid": 2, "hip": 0}[backend]
     assert capi.get_option(108) == want_backend
     assert capi.get_option(capi.OPT_ASYNC_UNMAP) == async_unmap
     capi.reset_stats()
     n, epp = 64, PAGE // 2
-    rng = random.Random(hash((backend, mode, async_unmap, extent_pages)) & 0xffff)
+    rng = random.Random(sum(map(ord, backend + mode + switch)) + 7 * async_unmap + extent_pages)   # (str hashes differ per process)
     stamp, serial = {}, 0
     for rnd in range(8):
         free = [i for i in range(n) if i not in stamp]
