@@ -370,6 +370,52 @@ def test_shrinking_the_budget_releases_pooled_handles(monkeypatch):
         vmm_ops.shutdown_kvcached()
 
 
+def test_the_physical_reserve_is_created_ahead_of_time_and_serves_a_growth_burst(monkeypatch):
+    """allocating VRAM the kernel has not cleared yet costs ~80 us per 2 MiB inside the allocation. With a
+    housekeeping thread around (every engine has one) the pool pre-creates KVCACHED_PHYS_RESERVE_MB of idle memory in the
+    background and never decays below it: a growth burst up to that size creates nothing on the caller's path."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "512")            # 256 pages of 2 MiB
+    monkeypatch.setenv("KVCACHED_POOL_IDLE_MS", "200")
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)          # starts the prealloc + watcher (housekeeping) threads
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    try:
+        vmm_ops.create_kv_tensors(256 * T.PAGE * 2, 1, DEV, 2, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=256 * 64, block_size=16, cell_size=2048, num_layers=2)
+        assert m._post_init_done.wait(10)
+        if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+            pytest.skip("the reserve is pre-created with the drm backend and pages straight from KFD")
+        t0 = time.time()
+        while time.time() - t0 < 5:                                  # a few 100 ms ticks (256 pages per tick at most)
+            held, out = capi.get_option(capi.OPT_POOL_HELD_PAGES), capi.get_option(capi.OPT_POOL_OUT_PAGES)
+            if held - out >= 256:
+                break
+            time.sleep(0.05)
+        assert held - out >= 256, (held, out)
+        time.sleep(0.6)                                               # three idle windows: the reserve is not decayed away
+        assert capi.get_option(capi.OPT_POOL_HELD_PAGES) - capi.get_option(capi.OPT_POOL_OUT_PAGES) >= 256
+        clean = False
+        for attempt in range(4):   # (the housekeeping thread may top the reserve up in the very 2 ms the burst takes: look again then)
+            before = capi.get_stats()
+            ids = m.alloc(40 * 64)                                   # 40 page ids = 160 slots: well inside the reserve
+            st = capi.get_stats()
+            assert st["pages_mapped"] - before["pages_mapped"] >= 100
+            clean = st["handles_created"] == before["handles_created"]
+            m.free(ids)
+            m.trim()
+            if clean:
+                break
+            time.sleep(0.5)
+        assert clean, "every growth burst created pages on the caller's path although the reserve was full"
+        del m
+    finally:
+        vmm_ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_golden_trace_with_async_unmap(monkeypatch):
     """Bookkeeping is synchronous, so the reference's golden trace (block ids, page offsets, counters) is still
     bit-exact with KVC_OPT_ASYNC_UNMAP on; after a flush the physical ledger matches the synchronous run."""
