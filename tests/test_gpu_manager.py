@@ -381,6 +381,7 @@ def test_the_physical_reserve_is_created_ahead_of_time_and_serves_a_growth_burst
     monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
     monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)          # starts the prealloc + watcher (housekeeping) threads
     vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    capi.reset_stats()
     try:
         vmm_ops.create_kv_tensors(256 * T.PAGE * 2, 1, DEV, 2, 2, 0, False)
         m = kcm.KVCacheManager(num_blocks=256 * 64, block_size=16, cell_size=2048, num_layers=2)
