@@ -24,8 +24,8 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 
-LIB_SRCS = ["c_api.cpp", "kv_allocator.cpp", "page_allocator.cpp", "kernels.hip", "index_kernels.hip"]
-LIB_DEPS = LIB_SRCS + ["common.hpp", "hip_vmm.hpp", "drm_vm.hpp", "kernels.hpp", "kv_allocator.hpp", "mem_info.hpp",
+LIB_SRCS = ["c_api.cpp", "kv_allocator.cpp", "gpu_context.cpp", "page_allocator.cpp", "kernels.hip", "index_kernels.hip"]
+LIB_DEPS = LIB_SRCS + ["common.hpp", "hip_vmm.hpp", "drm_vm.hpp", "extent_pool.hpp", "kernels.hpp", "kv_allocator.hpp", "mem_info.hpp",
                        "page_allocator.hpp", "../../include/kvcached_amd.h"]
 EXT_SRCS = ["vmm_ops.cpp"]
 

@@ -63,10 +63,13 @@ struct VmmCounters { // in pages
 // A physical page plus the creation order of its extent.
 // scrub_ticket: 0 = the page may hold old data and must be zeroed by whoever maps it; otherwise it has been zeroed (or is
 // being zeroed) by scrub number `scrub_ticket` on the owner's stream - wait for that one, write nothing.
+// wait_ticket: the last scrub that was ever queued on the page's extent - whoever hands the page out waits for it in any
+// case (a page that came back unscrubbed after a scrubbed life may still have that older fill in flight).
 struct Phys {
   phys_handle_t h{};
   uint64_t seq = 0;
   uint64_t scrub_ticket = 0;
+  uint64_t wait_ticket = 0;
 };
 
 struct ExtentDriver {
@@ -403,7 +406,7 @@ private:
       e.free_mask &= ~bit;
       old += (e.used_mask & bit) != 0;
       e.used_mask |= bit;
-      out[i] = Phys{piece_id(h, first + i, e.n), e.seq, (e.clean_mask & bit) ? std::max<uint64_t>(e.ticket, 1) : 0};
+      out[i] = Phys{piece_id(h, first + i, e.n), e.seq, (e.clean_mask & bit) ? std::max<uint64_t>(e.ticket, 1) : 0, e.ticket};
       e.clean_mask &= ~bit; // in somebody's hands now
     }
     free_pieces_ -= n;

@@ -12,29 +12,6 @@
 
 namespace kvc {
 
-// ------------------------------------------------------------------ globals
-Options &options() {
-  static Options o;
-  return o;
-}
-Stats &stats() {
-  static Stats s;
-  return s;
-}
-void Stats::reset() {
-  pages_mapped = pages_unmapped = 0;
-  map_calls = unmap_calls = map_ns = unmap_ns = 0;
-  fill_launches = fill_bytes = compact_launches = compact_bytes = 0;
-  tlb_shootdowns = shootdown_ns = 0;
-  index_launches = 0;
-  unmaps_queued = unmaps_cancelled = 0;
-  pages_scrubbed = pages_prescrubbed = 0;
-  t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
-  vmm.created = vmm.released = vmm.reused = 0;
-  std::lock_guard<std::mutex> g(mu);
-  fill_ms = compact_ms = 0;
-}
-
 namespace {
 std::mutex g_mu; // guards the registry below
 // Never destroyed: a process that ends without kvc_shutdown() must not tear GPU state down from static destructors -
@@ -63,574 +40,6 @@ GpuContext *context_for(int dev) {
   return it->second.get();
 }
 } // namespace
-
-// ------------------------------------------------------------------ GpuContext
-namespace {
-thread_local bool tl_background_thread = false; // set in the flusher / housekeeping threads
-}
-std::atomic<int64_t> &background_shootdowns() {
-  static std::atomic<int64_t> v{0};
-  return v;
-}
-
-GpuContext::GpuContext(int dev) : dev_(dev) {
-  HIP_CHECK(hipSetDevice(dev_));
-  int supports_vmm = 0;
-  HIP_CHECK(hipDeviceGetAttribute(&supports_vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev_));
-  if (!supports_vmm)
-    throw InvalidError("VMM is not supported on HIP device " + std::to_string(dev_) +
-                       ". kvcached requires GPU VMM support.");
-  auto prop = make_alloc_prop(dev_, false);
-  size_t gran = 0;
-  HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
-  if (gran == 0 || g_page_size % gran != 0)
-    throw InvalidError("Invalid page size: " + std::to_string(g_page_size) + " must be a multiple of HIP granularity " +
-                       std::to_string(gran));
-  HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&scrub_stream_, hipStreamNonBlocking));
-  if (env_bool("KVCACHED_KFD_TLB_FLUSH", true)) {
-    std::string why;
-    if (!kfd_flush_.open(dev_, &why))
-      KVC_LOG(LOG_WARNING, "direct KFD TLB flush unavailable (%s): invalidating through hipMalloc + hipFree", why.c_str());
-  }
-}
-
-GpuContext::~GpuContext() {
-  {
-    std::lock_guard<std::mutex> g(fl_mu_);
-    fl_stop_ = true;
-  }
-  fl_cv_.notify_all();
-  if (flusher_.joinable()) flusher_.join();
-  (void)hipSetDevice(dev_);
-  for (auto &t : inflight_) {
-    (void)hipEventDestroy(t.a);
-    (void)hipEventDestroy(t.b);
-  }
-  for (auto &e : free_events_) {
-    (void)hipEventDestroy(e.first);
-    (void)hipEventDestroy(e.second);
-  }
-  if (scrub_stream_) (void)hipStreamSynchronize(scrub_stream_); // no fill may be running on an alias that is about to go
-  extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
-  extent_pools_[1].clear();
-  for (auto &kv : zero_extents_) {
-    (void)DrmVm::instance().clear(reinterpret_cast<void *>(kv.second.alias), kv.second.pages * kv.first);
-    (void)DrmVm::instance().forget(kv.second.h);
-  }
-  zero_extents_.clear();
-  for (auto &a : arenas_) (void)hipMemAddressFree(a.base, a.size);
-  arenas_.clear();
-  if (scrub_stream_) (void)hipStreamDestroy(scrub_stream_);
-  kfd_flush_.close();
-  if (uniq_bitmap_) (void)hipFree(uniq_bitmap_);
-  if (uniq_header_) (void)hipFree(uniq_header_);
-  if (uniq_result_) (void)hipHostFree(uniq_result_);
-  if (stream_) (void)hipStreamDestroy(stream_);
-}
-
-void GpuContext::bind() const { HIP_CHECK(hipSetDevice(dev_)); }
-
-namespace {
-// hipMemGetInfo is ~0.25 us on MI355X: cheap enough to ask on every release batch.
-bool device_under_pressure() {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  static const double util = []() {
-    const char *e = std::getenv("KVCACHED_GPU_UTILIZATION");
-    return e ? std::atof(e) : 0.95;
-  }();
-  return free_b < static_cast<size_t>(total_b * (1.0 - util));
-}
-} // namespace
-
-ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
-  // Run-sized extents need a map offset (GEM_VA has one; HIP rejects it, ROCr ignores it), ranged unmaps and buffers of
-  // our own making: the drm backend with pages straight from KFD. Everything else works with single pages.
-  unsigned k = 1;
-  if (!exportable && vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && DrmVm::instance().can_clear())
-    k = (unsigned)std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, options().phys_chunk_pages.load()));
-  k = (unsigned)std::min<size_t>(k, std::max<size_t>(1, (256u << 20) / page_bytes)); // no buffer above 256 MiB (8 MiB pages, compound pages)
-  std::lock_guard<std::mutex> g(mu_);
-  auto &m = extent_pools_[exportable ? 1 : 0];
-  auto it = m.find(page_bytes);
-  if (it == m.end() || it->second->max_extent_pages() != k) {
-    // (re)made at the first use after an init that changed the extent size: no region exists then, every piece is home
-    ExtentDriver d;
-    const int dev = dev_;
-    const bool aliases = k > 1 && options().scrub_on_release.load() != 0; // (k > 1: drm backend, buffers of our own making)
-    d.create = [this, dev, page_bytes, exportable, aliases](size_t pages, uint64_t *tag) -> phys_handle_t {
-      if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
-        hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-      const phys_handle_t h = vmm_create(dev, pages * page_bytes, exportable, true, (unsigned)pages);
-      if (tag) *tag = 0;
-      if (tag && aliases) {
-        // The buffer's second, permanent mapping: the address its pages are zeroed through after their slots are gone.
-        // One more ioctl per buffer; failure only means that its pages are zeroed when they are mapped, as before.
-        if (void *bo = DrmVm::instance().find(h)) {
-          const uint64_t va = alias_alloc(pages * page_bytes);
-          if (va && DrmVm::instance().map(bo, reinterpret_cast<void *>(va), pages * page_bytes, 0) == 0)
-            *tag = va;
-          else if (va)
-            alias_free(va, pages * page_bytes);
-        }
-      }
-      return h;
-    };
-    d.prepare_release = [this, page_bytes](phys_handle_t, uint64_t tag, size_t pages) {
-      if (!tag) return;
-      wait_all_scrubs(); // nothing may still be writing through the alias
-      StaleAfter mark;   // a live translation goes away: the invalidation before_release performs covers it
-      if (DrmVm::instance().clear(reinterpret_cast<void *>(tag), pages * page_bytes) != 0)
-        KVC_LOG(LOG_ERROR, "dropping the alias mapping of a buffer failed");
-      alias_free(tag, pages * page_bytes);
-    };
-    d.release = [](phys_handle_t h) {
-      const bool ok = vmm_try_release(h);
-      if (!ok) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
-      (void)hipGetLastError();
-      return ok;
-    };
-    d.before_release = [this]() { flush_deferred_shootdown(); }; // memory leaves the process: no translation of it may survive
-    d.under_pressure = device_under_pressure;
-    m[page_bytes] = std::make_unique<ExtentPool>(page_bytes, k, std::move(d), &stats().vmm);
-    it = m.find(page_bytes);
-    it->second->set_defer_eviction(housekeepers_.load() > 0);
-  }
-  it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
-  it->second->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
-  return it->second.get();
-}
-
-std::vector<ExtentPool *> GpuContext::all_pools() {
-  std::lock_guard<std::mutex> g(mu_);
-  std::vector<ExtentPool *> ps;
-  for (auto &m : extent_pools_)
-    for (auto &kv : m) ps.push_back(kv.second.get());
-  return ps;
-}
-
-void GpuContext::drain_pools() {
-  for (auto *p : all_pools()) p->drain(0);
-}
-
-size_t GpuContext::idle_pool_bytes() {
-  size_t b = 0;
-  for (auto *p : all_pools()) b += p->idle_bytes();
-  return b;
-}
-
-void GpuContext::add_housekeeper(int delta) {
-  const bool on = housekeepers_.fetch_add(delta) + delta > 0;
-  for (auto *p : all_pools()) {
-    p->set_defer_eviction(on);
-    if (!on) p->trim_to_cap((size_t)-1); // nobody will do it later
-  }
-}
-
-void GpuContext::housekeeping() {
-  auto ps = all_pools();
-  if (ps.empty()) return;
-  (void)hipSetDevice(dev_);
-  tl_background_thread = true; // the allocator's watcher thread
-  try {
-    flush_deferred_shootdown(); // the invalidation unmap batches left to this thread (KVCACHED_ASYNC_SHOOTDOWN)
-  } catch (const std::exception &e) {
-    KVC_LOG(LOG_ERROR, "housekeeping: TLB invalidation failed: %s", e.what());
-  }
-  if (device_under_pressure()) {
-    for (auto *p : ps) p->drain(0);
-    return;
-  }
-  // Releasing memory the GPU has touched costs 50-70 us per 2 MiB (the kernel wipes it) and driver calls of one
-  // process do not overlap: 256 pages per 100 ms tick keeps this thread's share of the driver under ~15 % while
-  // still returning 5 GiB/s.
-  constexpr size_t kPerTick = 256;
-  for (auto *p : ps) p->trim_to_cap(kPerTick); // what release_batch left above the cap (deferred eviction)
-  const int64_t idle_ms = options().pool_idle_ms.load();
-  const size_t reserve_b = (size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load());
-  for (auto *p : ps) {
-    // the reserve belongs to the pool the engine's own pages come from (not to the exportable twin)
-    const size_t floor_pages = (p == ps[0] || ps.size() == 1) ? reserve_b / p->page_bytes() : 0;
-    if (idle_ms > 0) p->decay(now_ns(), idle_ms * 1000000ll, kPerTick, floor_pages);
-    // Growth into VRAM the kernel has not cleared yet costs ~80 us per 2 MiB inside the allocation (one SDMA ring,
-    // ~30 GB/s: profiles/r02_create_cost.jsonl); this thread pays that ahead of time, off every caller's path.
-    if (floor_pages) p->refill_reserve(floor_pages, kPerTick);
-  }
-}
-
-void GpuContext::begin_timed(hipStream_t s, int kind) {
-  if (!options().profile.load()) return;
-  std::lock_guard<std::mutex> g(mu_);
-  Timed t{nullptr, nullptr, kind};
-  if (!free_events_.empty()) {
-    t.a = free_events_.back().first;
-    t.b = free_events_.back().second;
-    free_events_.pop_back();
-  } else {
-    HIP_CHECK(hipEventCreate(&t.a));
-    HIP_CHECK(hipEventCreate(&t.b));
-  }
-  HIP_CHECK(hipEventRecord(t.a, s));
-  inflight_.push_back(t);
-}
-void GpuContext::end_timed(hipStream_t s) {
-  if (!options().profile.load()) return;
-  std::lock_guard<std::mutex> g(mu_);
-  if (!inflight_.empty()) HIP_CHECK(hipEventRecord(inflight_.back().b, s));
-}
-void GpuContext::harvest() {
-  std::lock_guard<std::mutex> g(mu_);
-  if (inflight_.empty()) return;
-  double fill = 0, comp = 0;
-  std::vector<Timed> still;
-  for (auto &t : inflight_) {
-    if (hipEventQuery(t.b) == hipErrorNotReady) { // a launch on the other stream that has not finished: next time
-      (void)hipGetLastError();
-      still.push_back(t);
-      continue;
-    }
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) (t.kind == 0 ? fill : comp) += ms;
-    (void)hipGetLastError();
-    free_events_.emplace_back(t.a, t.b);
-  }
-  inflight_.swap(still);
-  std::lock_guard<std::mutex> g2(stats().mu);
-  stats().fill_ms += fill;
-  stats().compact_ms += comp;
-}
-
-void GpuContext::zero_fill(void *const *pages, size_t n, size_t page_bytes, hipStream_t s) {
-  if (!s) s = stream_;
-  const int variant = (int)options().fill_variant.load();
-  for (size_t i = 0; i < n; i += kMaxPtrsPerLaunch) {
-    int k = (int)std::min<size_t>(kMaxPtrsPerLaunch, n - i);
-    begin_timed(s, 0);
-    HIP_CHECK(launch_zero_fill_pages(pages + i, k, page_bytes, s, variant));
-    end_timed(s);
-    stats().fill_launches++;
-    stats().fill_bytes += (int64_t)k * (int64_t)page_bytes;
-  }
-}
-
-uint64_t GpuContext::scrub(const uint64_t *alias_addrs, size_t n, size_t page_bytes) {
-  std::vector<void *> ptrs;
-  ptrs.reserve(n);
-  for (size_t i = 0; i < n; ++i)
-    if (alias_addrs[i]) ptrs.push_back(reinterpret_cast<void *>(alias_addrs[i]));
-  if (ptrs.empty()) return 0;
-  std::lock_guard<std::mutex> g(scrub_mu_);
-  bind();
-  zero_fill(ptrs.data(), ptrs.size(), page_bytes, scrub_stream_);
-  stats().pages_scrubbed += (int64_t)ptrs.size();
-  return scrub_issued_.fetch_add(1) + 1;
-}
-
-void GpuContext::wait_scrub(uint64_t ticket) {
-  if (!ticket || scrub_done_.load() >= ticket) return;
-  const uint64_t covered = scrub_issued_.load(); // every scrub launched so far is ahead of the sync below
-  HIP_CHECK(hipStreamSynchronize(scrub_stream_));
-  uint64_t cur = scrub_done_.load();
-  while (cur < covered && !scrub_done_.compare_exchange_weak(cur, covered)) {
-  }
-  harvest();
-}
-
-phys_handle_t GpuContext::zero_extent(size_t page_bytes, size_t *pages) {
-  std::lock_guard<std::mutex> g(mu_);
-  auto it = zero_extents_.find(page_bytes);
-  if (it != zero_extents_.end()) {
-    *pages = it->second.pages;
-    return it->second.h;
-  }
-  if (vmm_backend() != kVmmDrm || !DrmVm::instance().kfd_ready() || !DrmVm::instance().can_clear()) return 0;
-  // 64 pages (128 MiB of zeros for 2 MiB pages: 0.04 % of the HBM), never more than 256 MiB
-  const size_t n = std::max<size_t>(1, std::min<size_t>(kMaxExtentPages, (256u << 20) / page_bytes));
-  phys_handle_t h = 0;
-  uint64_t alias = 0;
-  try {
-    h = DrmVm::instance().create(n * page_bytes, (unsigned)n);
-    void *bo = DrmVm::instance().find(h);
-    alias = alias_alloc(n * page_bytes);
-    if (!bo || !alias || DrmVm::instance().map(bo, reinterpret_cast<void *>(alias), n * page_bytes, 0) != 0) throw GpuError("mapping the zero extent failed");
-    std::vector<void *> ptrs;
-    for (size_t i = 0; i < n; ++i) ptrs.push_back(reinterpret_cast<void *>(alias + i * page_bytes));
-    bind();
-    zero_fill(ptrs.data(), ptrs.size(), page_bytes, stream_); // what the driver hands out is zero today; not a documented guarantee
-    HIP_CHECK(hipStreamSynchronize(stream_));
-  } catch (const std::exception &e) {
-    KVC_LOG(LOG_WARNING, "no zero extent (%s): compat mode aliases sharded zero pages through ROCr", e.what());
-    if (alias) alias_free(alias, n * page_bytes);
-    if (h) (void)DrmVm::instance().forget(h);
-    (void)hipGetLastError();
-    return 0;
-  }
-  zero_extents_[page_bytes] = ZeroExtent{h, n, alias};
-  *pages = n;
-  return h;
-}
-
-uint64_t GpuContext::alias_alloc(size_t bytes) {
-  std::lock_guard<std::mutex> g(arena_mu_);
-  auto it = alias_free_.find(bytes);
-  if (it != alias_free_.end() && !it->second.empty()) {
-    const uint64_t va = it->second.back();
-    it->second.pop_back();
-    return va;
-  }
-  constexpr size_t kArena = 64ull << 30;
-  if (arenas_.empty() || arenas_.back().size - arenas_.back().used < bytes) {
-    void *p = nullptr;
-    const size_t want = std::max(kArena, bytes);
-    if (hipMemAddressReserve(&p, want, kBasePage, nullptr, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
-    }
-    arenas_.push_back(Arena{static_cast<char *>(p), want, 0});
-  }
-  Arena &a = arenas_.back();
-  const uint64_t va = reinterpret_cast<uint64_t>(a.base + a.used);
-  a.used += bytes;
-  return va;
-}
-
-void GpuContext::alias_free(uint64_t va, size_t bytes) {
-  std::lock_guard<std::mutex> g(arena_mu_);
-  alias_free_[bytes].push_back(va);
-}
-
-void GpuContext::compact(void *const *bases, size_t n_regions, const int64_t *src, const int64_t *dst, size_t n_moves,
-                         size_t block_bytes, hipStream_t s) {
-  if (!s) s = stream_;
-  const int variant = (int)options().compact_variant.load();
-  for (size_t r = 0; r < n_regions; r += kMaxRegionsPerLaunch) {
-    int nr = (int)std::min<size_t>(kMaxRegionsPerLaunch, n_regions - r);
-    for (size_t m = 0; m < n_moves; m += kMaxMovesPerLaunch) {
-      int nm = (int)std::min<size_t>(kMaxMovesPerLaunch, n_moves - m);
-      begin_timed(s, 1);
-      HIP_CHECK(launch_compact_blocks(bases + r, nr, src + m, dst + m, nm, block_bytes, s, variant));
-      end_timed(s);
-      stats().compact_launches++;
-      stats().compact_bytes += 2ll * nr * nm * (int64_t)block_bytes;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- block id <-> token index glue
-namespace {
-// Block ids beyond the kernarg budget go through a stream-ordered device buffer (rare: > 1024 new blocks in
-// one scheduler step). hipMemcpyAsync from pageable memory returns once the source has been consumed.
-struct StagedIds {
-  int64_t *dev = nullptr;
-  hipStream_t s;
-  StagedIds(const int64_t *host, size_t n, hipStream_t stream) : s(stream) {
-    HIP_CHECK(hipMallocAsync(reinterpret_cast<void **>(&dev), n * sizeof(int64_t), s));
-    hipError_t st = hipMemcpyAsync(dev, host, n * sizeof(int64_t), hipMemcpyHostToDevice, s);
-    if (st != hipSuccess) {
-      (void)hipFreeAsync(dev, s);
-      HIP_CHECK(st);
-    }
-  }
-  ~StagedIds() {
-    if (dev) (void)hipFreeAsync(dev, s);
-  }
-};
-} // namespace
-
-void GpuContext::expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s) {
-  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
-  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
-  for (size_t i = 0; i < n; i += kMaxIdsPerLaunch) {
-    const size_t k = std::min<size_t>(kMaxIdsPerLaunch, n - i);
-    HIP_CHECK(launch_expand_block_ids(ids + i, nullptr, k, tpb, out + i * (size_t)tpb, s));
-    stats().index_launches++;
-  }
-}
-
-void GpuContext::alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
-                                      const int64_t *ids, size_t n_ids, int64_t tpb, int64_t *out, size_t out_len,
-                                      hipStream_t s) {
-  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
-  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
-  if (n_ids <= (size_t)kMaxIdsPerLaunch) {
-    HIP_CHECK(launch_alloc_extend(ids, nullptr, n_ids, pre_lens, seq_lens, last_loc, bs, tpb, out, out_len, s));
-  } else {
-    StagedIds staged(ids, n_ids, s);
-    HIP_CHECK(launch_alloc_extend(nullptr, staged.dev, n_ids, pre_lens, seq_lens, last_loc, bs, tpb, out, out_len, s));
-  }
-  stats().index_launches++;
-}
-
-void GpuContext::alloc_decode_indices(const int64_t *seq_lens, const int64_t *last_loc, size_t bs, const int64_t *ids,
-                                      size_t n_ids, int64_t tpb, int64_t *out, hipStream_t s) {
-  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
-  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
-  if (n_ids <= (size_t)kMaxIdsPerLaunch) {
-    HIP_CHECK(launch_alloc_decode(ids, nullptr, n_ids, seq_lens, last_loc, bs, tpb, out, s));
-  } else {
-    StagedIds staged(ids, n_ids, s);
-    HIP_CHECK(launch_alloc_decode(nullptr, staged.dev, n_ids, seq_lens, last_loc, bs, tpb, out, s));
-  }
-  stats().index_launches++;
-}
-
-void GpuContext::reset_unique_scratch() {
-  static const unsigned init[4] = {0xffffffffu, 0u, 0u, 0u};
-  if (uniq_bitmap_) (void)hipMemset(uniq_bitmap_, 0, uniq_words_ * sizeof(unsigned));
-  if (uniq_header_) (void)hipMemcpy(uniq_header_, init, sizeof(init), hipMemcpyHostToDevice);
-}
-
-int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, int64_t n_blocks, int64_t *out_host,
-                                     size_t cap, hipStream_t s) {
-  // (s == NULL is the device's default stream here - what torch.cuda.current_stream() is unless the caller switched: these
-  // kernels consume and produce tensors of the caller's stream, the library's own non-blocking stream would race with them)
-  if (tpb <= 0 || n_blocks <= 0) throw InvalidError("tokens_per_block and num_blocks must be positive");
-  std::lock_guard<std::mutex> g(uniq_mu_);
-  const size_t words = ((size_t)n_blocks + 31) / 32;
-  if (words > uniq_words_) {
-    if (uniq_bitmap_) HIP_CHECK(hipFree(uniq_bitmap_));
-    uniq_bitmap_ = nullptr;
-    uniq_words_ = 0;
-    const size_t want = std::max<size_t>(words, 4096);
-    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&uniq_bitmap_), want * sizeof(unsigned)));
-    uniq_words_ = want;
-    if (!uniq_header_) HIP_CHECK(hipMalloc(&uniq_header_, 16));
-    reset_unique_scratch();
-    HIP_CHECK(hipDeviceSynchronize());
-  }
-  const size_t need = std::min<size_t>(n, (size_t)n_blocks) + 1;
-  if (need > uniq_result_cap_) {
-    if (uniq_result_) HIP_CHECK(hipHostFree(uniq_result_));
-    uniq_result_ = nullptr;
-    uniq_result_cap_ = 0;
-    const size_t want = std::max<size_t>(need, 8192);
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&uniq_result_), want * sizeof(int64_t), hipHostMallocDefault));
-    uniq_result_cap_ = want;
-  }
-  void *result_dev = nullptr;
-  HIP_CHECK(hipHostGetDevicePointer(&result_dev, uniq_result_, 0));
-  try {
-    HIP_CHECK(launch_unique_block_ids(idx, n, tpb, n_blocks, uniq_bitmap_, uniq_header_, static_cast<int64_t *>(result_dev),
-                                      uniq_result_cap_ - 1, s));
-    stats().index_launches += 2;
-    HIP_CHECK(hipStreamSynchronize(s));
-  } catch (...) {
-    (void)hipDeviceSynchronize();
-    reset_unique_scratch();
-    throw;
-  }
-  const int64_t count = uniq_result_[0];
-  if (count < 0)
-    throw InvalidError(std::to_string(-count) + " token indices are outside [0, num_blocks * tokens_per_block)");
-  if (out_host && (size_t)count <= cap) std::copy(uniq_result_ + 1, uniq_result_ + 1 + count, out_host);
-  return count;
-}
-
-void GpuContext::ensure_flushed() {
-  std::lock_guard<std::mutex> g(flush_mu_);
-  if (tlb_stale().load()) do_shootdown();
-}
-
-void GpuContext::request_async_flush() {
-  {
-    std::lock_guard<std::mutex> g(fl_mu_);
-    if (fl_stop_) return;
-    if (!flusher_.joinable()) flusher_ = std::thread([this] { flusher_loop(); });
-    fl_kick_ = true;
-  }
-  fl_cv_.notify_one();
-}
-
-void GpuContext::flusher_loop() {
-  (void)hipSetDevice(dev_);
-  tl_background_thread = true;
-  std::unique_lock<std::mutex> lk(fl_mu_);
-  while (!fl_stop_) {
-    fl_cv_.wait(lk, [&] { return fl_stop_ || fl_kick_; });
-    if (fl_stop_) break;
-    fl_kick_ = false;
-    lk.unlock();
-    try {
-      ensure_flushed();
-    } catch (const std::exception &e) {
-      KVC_LOG(LOG_ERROR, "background TLB invalidation failed: %s", e.what());
-      (void)hipGetLastError();
-    }
-    lk.lock();
-  }
-}
-
-// Unconditional invalidation. Serialised with ensure_flushed(): the flag is cleared when an invalidation STARTS, so
-// whoever finds it clear must be able to rely on that invalidation having finished - both take flush_mu_.
-void GpuContext::tlb_shootdown() {
-  std::lock_guard<std::mutex> g(flush_mu_);
-  do_shootdown();
-}
-
-void GpuContext::ensure_flushed_through(uint64_t epoch) {
-  // (at most two rounds: an invalidation that was already in flight when the translation went away does not count,
-  // the one after it does)
-  for (int i = 0; i < 4 && !flushed_through(epoch); ++i) {
-    std::lock_guard<std::mutex> g(flush_mu_);
-    if (flushed_through(epoch)) break;
-    do_shootdown();
-  }
-}
-
-void GpuContext::do_shootdown() {
-  tlb_stale().store(false); // before the flush: an unmap racing with it stays owed
-  const uint64_t epoch = flush_started_.fetch_add(1) + 1;
-  struct Done {
-    std::atomic<uint64_t> &d;
-    uint64_t e;
-    bool ok = false;
-    ~Done() {
-      if (ok) d.store(std::max(d.load(), e)); // (serialised by flush_mu_)
-    }
-  } done{flush_done_, epoch};
-  if (!options().tlb_shootdown.load()) {
-    done.ok = true;
-    return;
-  }
-  static const bool broken_for_test = env_bool("KVCACHED_TEST_BREAK_TLB_FLUSH", false); // hook: the init self test must notice
-  const int64_t t0 = now_ns();
-  if (broken_for_test) {
-    // nothing: what a runtime that stopped flushing would look like
-  } else if (kfd_flush_.ready()) {
-    // The ioctl pair that ends in KFD's heavyweight flush, on our own buffer: nothing between us and the kernel can
-    // answer it from a cache.
-    if (!kfd_flush_.flush()) throw GpuError(std::string("KFD TLB flush failed: ") + strerror(errno));
-  } else {
-    // Fallback where /dev/kfd cannot be driven directly: an allocation that reaches KFD. 2 MiB is the smallest size
-    // ROCr does not serve from its sub-allocator (measured: 4 KiB has no effect, 2 MiB ~0.22 ms). A real trip to the
-    // kernel takes >150 us on MI355X; one that returns in <20 us was served from a cache and invalidated nothing, so a
-    // block too large for any cache is used instead. (Only this fallback watches the clock; init's self test has
-    // checked that it invalidates at all.)
-    void *p = nullptr;
-    HIP_CHECK(hipMalloc(&p, 2u << 20));
-    HIP_CHECK(hipFree(p));
-    if (now_ns() - t0 < 20000) {
-      static std::atomic<bool> warned{false};
-      if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: 2 MiB allocation did not reach the driver; using 64 MiB blocks");
-      HIP_CHECK(hipMalloc(&p, 64u << 20));
-      HIP_CHECK(hipFree(p));
-    }
-  }
-  done.ok = true;
-  stats().tlb_shootdowns++;
-  if (tl_background_thread) background_shootdowns()++;
-  stats().shootdown_ns += now_ns() - t0;
-}
-
-void GpuContext::sync(hipStream_t s) {
-  if (!s) s = stream_;
-  HIP_CHECK(hipStreamSynchronize(s));
-  harvest();
-}
 
 // The hybrid backend rests on one property of the HIP runtime: once it has recorded a mapping for a VA it keeps
 // addressing that VA in copies and memsets, whatever ROCr has mapped there since. Checked once per init on a
@@ -1796,6 +1205,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       done.push_back(s);
       if (!needs_access) { // mapped readable+writable in one ioctl (drm backend): straight to the fill queue
         if (always_flush) dirty_tlb = true;
+        max_ticket = std::max(max_ticket, ph.wait_ticket); // (any older fill through the alias must be over before the caller writes)
         if (fill && ph.scrub_ticket) {
           max_ticket = std::max(max_ticket, ph.scrub_ticket);
           stats().pages_prescrubbed++;
@@ -1863,6 +1273,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
             r.seq[s.index] = got[k].seq;
             r.mapped[s.index] = 1;
             done.push_back(s);
+            max_ticket = std::max(max_ticket, got[k].wait_ticket);
             if (fill && got[k].scrub_ticket) {
               max_ticket = std::max(max_ticket, got[k].scrub_ticket);
               stats().pages_prescrubbed++;

@@ -183,6 +183,7 @@ private:
     size_t pages;
     uint64_t alias;
   };
+  std::mutex zero_mu_;
   std::map<size_t, ZeroExtent> zero_extents_; // by page size
   std::vector<Timed> inflight_;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events_;

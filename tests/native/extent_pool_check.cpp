@@ -266,6 +266,7 @@ int main() {
     h.pool.release_batch(q, 3);               // used and returned unscrubbed: dirty again
     REQUIRE(h.pool.acquire_run(8, q, &rec, false) == 8, "all eight");
     for (int i = 0; i < 8; ++i) REQUIRE(q[i].scrub_ticket == (i < 3 ? 0u : 9u), "page %d after a dirty return", i);
+    for (int i = 0; i < 8; ++i) REQUIRE(q[i].wait_ticket == 9u, "the older scrub of the extent is still waited for (page %d)", i);
     h.pool.release_batch(q, 8, 11);
     h.pool.drain(0);
     REQUIRE(h.drv.prepared == 1 && h.drv.live.empty(), "the alias is dropped before the buffer goes back");

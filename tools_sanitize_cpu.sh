@@ -10,7 +10,7 @@ cd "$(dirname "$0")"
 mkdir -p build/$SAN
 (cd kvcached_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -pthread \
     -Xarch_host -fsanitize=$SAN -Xarch_host -fno-omit-frame-pointer -x hip \
-    c_api.cpp kv_allocator.cpp page_allocator.cpp kernels.hip index_kernels.hip -o ../../build/$SAN/libkvcached_amd.so -L/opt/rocm/lib -lhsa-runtime64 -ldl)
+    c_api.cpp kv_allocator.cpp gpu_context.cpp page_allocator.cpp kernels.hip index_kernels.hip -o ../../build/$SAN/libkvcached_amd.so -L/opt/rocm/lib -lhsa-runtime64 -ldl)
 cp kvcached_amd/libkvcached_amd.so build/libkvcached_amd.so.bak
 restore() { cp build/libkvcached_amd.so.bak kvcached_amd/libkvcached_amd.so; sleep 1; touch kvcached_amd/vmm_ops.*.so; }
 trap restore EXIT
