@@ -184,7 +184,7 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         return {"elapsed": elapsed, "per_step": per_map, "per_unmap": per_unmap, "stats": st, "reserve_s": pool.reserve_s,
                 "window_GiB": pool.size / GiB, "burst": burst,
                 "backend_in_effect": {0: "hip", 2: "hybrid", 3: "drm"}.get(int(capi.get_option(108)), "?"),
-                "kfd_create": int(capi.get_option(110)), "kfd_tlb_flush": int(capi.get_option(118)),
+                "kfd_create": int(capi.get_option(110)), "kfd_tlb_flush": int(capi.get_option(118)), "prt": int(capi.get_option(128)),
                 "max_extent_pages": int(capi.get_option(119)), "create_split": create_split}
     finally:
         pool.close()
@@ -543,6 +543,7 @@ def main():
                                    "library's pool: the timed steps create none (handles_created) - allocation from the driver "
                                    "is what growth_burst_* measure",
                        "kfd_create": res["kfd_create"], "kfd_tlb_flush": res["kfd_tlb_flush"], "max_extent_pages": res["max_extent_pages"],
+                       "unbacked_va": "PRT mapping (reads 0, writes dropped, no fault)" if res["prt"] else ("zero aliases" if args.mode == "compat" else "unmapped"),
                        "mode": args.mode, "vmm_backend": res["backend_in_effect"] if not rehearsal else "none (cpu device)", "vmm_backend_requested": args.backend, "page_MiB": 2, "batch_pages": BATCH_PAGES,
                        "window_GiB": res["window_GiB"], "per_gpu_bytes_per_step": BATCH_PAGES * PAGE,
                        "fanout": f"{backend} broadcast + all-reduce(min)" if use_dist else "local"},
@@ -571,7 +572,9 @@ def main():
                     "extents_up_to_64_pages": V(env={"KVCACHED_PHYS_CHUNK_PAGES": "64"}),
                     "unmap_waits_for_its_own_tlb_invalidation": V(env={"KVCACHED_ASYNC_SHOOTDOWN": "false"}),
                     "tlb_flush_through_hipMalloc_instead_of_kfd": V(env={"KVCACHED_KFD_TLB_FLUSH": "false"}),
+                    "zero_extent_instead_of_prt": V(env={"KVCACHED_PRT": "false"}),
                     "lazy_mode_opt_in": V(mode="lazy"),
+                    "lazy_mode_unmapped_va_instead_of_prt_round1": V(mode="lazy", env={"KVCACHED_PRT": "false"}),
                     "lazy_mode_map_waits_for_all_invalidations": V(mode="lazy", env={"KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES": "true"}),
                     "lazy_mode_fill_in_the_map_call": V(mode="lazy", env={"KVCACHED_SCRUB_ON_RELEASE": "false"}),
                     "compat_sharded_zero_pages_through_rocr_round1": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false"}),

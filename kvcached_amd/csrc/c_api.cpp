@@ -179,10 +179,16 @@ int64_t kvc_get_option(int opt) {
     GpuContext *ctx = KvAllocator::gpu();
     return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().extent_pages_now : 0;
   }
-  case 127: { // pages of the zero extent behind compat-mode regions (0: none - sharded zero pages through ROCr; read-only)
+  case 127: { // pages of the zero extent behind compat-mode regions (0: none - PRT, or sharded zero pages through ROCr; read-only)
     GpuContext *ctx = KvAllocator::gpu();
-    size_t pages = 0;
-    return ctx && options().zero_backfill.load() && ctx->zero_extent(KvAllocator::page_size(), &pages) ? (int64_t)pages : 0;
+    return ctx ? (int64_t)ctx->zero_extent_pages(KvAllocator::page_size()) : 0;
+  }
+  case 128: { // unbacked slots of group 0 are PRT mappings: reads return 0, writes are dropped, nothing faults (read-only)
+    try {
+      return KvAllocator::initialized() && KvAllocator::global(0)->uses_prt() ? 1 : 0;
+    } catch (...) {
+      return 0;
+    }
   }
   case 125: return stats().pages_scrubbed;    // pages zeroed on their way back (read-only; reset with the stats)
   case 126: return stats().pages_prescrubbed; // pages a map call handed out without launching a fill for them

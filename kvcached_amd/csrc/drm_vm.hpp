@@ -420,6 +420,15 @@ public:
   int replace(void *bo, void *va, size_t size, uint64_t offset) {
     return api_.bo_va_op(bo, offset, size, reinterpret_cast<uint64_t>(va), 0, kVaOpReplace);
   }
+  // A range with no buffer behind it and AMDGPU_VM_PAGE_PRT ("partially resident"): the PTEs are invalid with the PRT bit
+  // set - reads return 0, writes are dropped, nothing faults (what Vulkan's sparse resources rest on; checked for
+  // compute kernels, blit and copy-engine hipMemcpy and hipMemset on gfx950 by tools/prt_probe.cpp). The rest state of
+  // unbacked KV slots: "reads as zeros" without a zero page, and - an invalid translation is never cached - backing such
+  // a slot needs no TLB invalidation. `replace`: drop or split whatever is mapped in the range first.
+  int map_prt(void *va, size_t size, bool replace = false) {
+    if (!can_clear()) return -ENOSYS;
+    return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), kVmPagePrt, replace ? kVaOpReplace : kVaOpMap);
+  }
   bool can_clear() const { return api_.bo_va_op_raw != nullptr && dev_ != nullptr; }
   int clear(void *va, size_t size) { return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpClear); }
 
@@ -462,6 +471,7 @@ private:
   }
   static constexpr int kHandleTypeDmaBufFd = 2;        // amdgpu_bo_handle_type_dma_buf_fd
   static constexpr uint32_t kVaOpMap = 1, kVaOpUnmap = 2, kVaOpClear = 3, kVaOpReplace = 4; // AMDGPU_VA_OP_MAP / _UNMAP / _CLEAR / _REPLACE
+  static constexpr uint64_t kVmPagePrt = 1u << 4;                                              // AMDGPU_VM_PAGE_PRT
   struct Api {
     int (*device_initialize)(int, uint32_t *, uint32_t *, void **) = nullptr;
     int (*device_deinitialize)(void *) = nullptr;

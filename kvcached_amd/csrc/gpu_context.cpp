@@ -343,6 +343,12 @@ phys_handle_t GpuContext::zero_extent(size_t page_bytes, size_t *pages) {
   return h;
 }
 
+size_t GpuContext::zero_extent_pages(size_t page_bytes) {
+  std::lock_guard<std::mutex> g(zero_mu_);
+  auto it = zero_extents_.find(page_bytes);
+  return it == zero_extents_.end() ? 0 : it->second.pages;
+}
+
 uint64_t GpuContext::alias_alloc(size_t bytes) {
   std::lock_guard<std::mutex> g(arena_mu_);
   auto it = alias_free_.find(bytes);

@@ -286,8 +286,17 @@ inline void vmm_map_pieces(void *va, size_t piece_bytes, size_t count, phys_hand
 }
 // The same over slots that currently show something else (compat mode: aliases of the zero extent): whatever is mapped in
 // the range is dropped or split and the pieces take its place, in ONE ioctl (AMDGPU_VA_OP_REPLACE).
-inline void vmm_replace_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first) {
-  StaleAfter mark; // live translations are replaced
+// `live`: the translations being replaced are valid ones (zero aliases) - PRT entries are not, and owe no invalidation.
+inline void vmm_replace_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first, bool live) {
+  struct MaybeStale {
+    bool on;
+    explicit MaybeStale(bool b) : on(b) {
+      if (on) tlb_stale().store(true);
+    }
+    ~MaybeStale() {
+      if (on) tlb_stale().store(true);
+    }
+  } mark(live);
   unsigned piece = 0;
   void *bo = vmm_direct_bo(h_first, &piece);
   if (!bo) throw GpuError("vmm_replace_pieces: not a direct DRM buffer");

@@ -634,7 +634,45 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // reservation; on ROCm hipMemUnmap of an alias costs O(aliases of that handle) (~6 ns each: 37 us
 // per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
 // the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
+// The rest state of unbacked slots on the drm backend: PRT (DrmVm::map_prt). One ioctl for the whole region.
+bool KvAllocator::prt_all(KvRegion &r) {
+  if (!dev_.is_gpu || vmm_backend() != kVmmDrm || !DrmVm::instance().can_clear() || !env_bool("KVCACHED_PRT", true)) return false;
+  hipDeviceProp_t prop{};
+  if (hipGetDeviceProperties(&prop, ctx_->dev()) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    (void)hipGetLastError();
+    return false; // what a PRT page does to a load is a property of the GPU: checked on gfx950 (tools/prt_probe.cpp), nowhere else
+  }
+  // HIP must have been introduced to every slot BEFORE the range is occupied (its placeholder mapping cannot overlap ours)
+  for (size_t i = 0; i < r.num_slots(); ++i)
+    if (vmm_hip_registered()) register_slot(r, i);
+  const int rc = DrmVm::instance().map_prt(r.base, r.size);
+  if (rc != 0) {
+    KVC_LOG(LOG_WARNING, "PRT mapping refused (%s): unbacked slots fall back to %s", strerror(rc < 0 ? -rc : rc),
+            options().zero_backfill.load() ? "zero aliases" : "unmapped VA");
+    return false;
+  }
+  r.prt = true;
+  return true;
+}
+
+int KvAllocator::rest_replace(KvRegion &r, size_t first, size_t n) {
+  StaleAfter mark; // whatever was mapped there was a live translation
+  char *va = r.base + first * r.page_size;
+  if (r.prt) return DrmVm::instance().map_prt(va, n * r.page_size, /*replace=*/true);
+  return DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), va, n * r.page_size, (first % r.zx_pages) * r.page_size);
+}
+
+int KvAllocator::rest_map(KvRegion &r, size_t first, size_t n) {
+  char *va = r.base + first * r.page_size;
+  if (r.prt) return DrmVm::instance().map_prt(va, n * r.page_size);
+  return DrmVm::instance().map(DrmVm::instance().find(r.zx_handle), va, n * r.page_size, (first % r.zx_pages) * r.page_size);
+}
+
 void KvAllocator::backfill_all(KvRegion &r) {
+  if (prt_all(r)) { // "reads as zeros" from the page tables themselves: no zero page, no invalidation on the map path
+    r.backfilled = true;
+    return;
+  }
   // drm backend: one buffer of zeros, a whole group of slots aliased per ioctl, no per-slot object anywhere (§4.2):
   // 2 304 ioctls for the 147 k slots of a 288 GiB reservation instead of 147 k map + set_access pairs.
   if (env_bool("KVCACHED_ZERO_EXTENT", true)) {
@@ -732,7 +770,7 @@ void KvAllocator::register_slot(KvRegion &r, size_t slot) {
 // (hipMemAddressFree and hipMemRelease expect that). Everything of ours inside a registered unit - pages, zero aliases -
 // is unmapped first; then a stand-in of the unit's size is mapped through ROCr for HIP's unmap to remove.
 void KvAllocator::unregister_slots(KvRegion &r) {
-  if (r.zx) { // pages and zero aliases alike are DRM mappings of ours: one ranged CLEAR drops them all
+  if (r.rest_direct()) { // pages and the rest state (PRT, zero aliases) alike are DRM mappings of ours: one ranged CLEAR drops them all
     StaleAfter mark;
     if (DrmVm::instance().clear(r.base, r.size) != 0) KVC_LOG(LOG_ERROR, "dropping the mappings of %s failed", r.name.c_str());
   }
@@ -749,7 +787,7 @@ void KvAllocator::unregister_slots(KvRegion &r) {
     char *va = r.base + first * r.page_size;
     for (size_t i = first; i < first + count; ++i) {
       char *sva = r.base + i * r.page_size;
-      if (r.zx) continue; // (cleared above)
+      if (r.rest_direct()) continue; // (cleared above)
       if (r.mapped[i]) {
         if (!vmm_try_unmap(sva, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
       } else if (r.backfilled) {
@@ -864,7 +902,10 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
     for (auto &r : layers_) destroy_region(*r);
     layers_.clear();
     auto r = make_region("kv_contiguous", aligned * (size_t)num_layers, region_page);
-    if (backfill) backfill_all(*r);
+    if (backfill)
+      backfill_all(*r);
+    else
+      (void)prt_all(*r); // lazy mode: unbacked VA does not fault either where PRT is to be had
     out.push_back({r->base, r->size});
     layers_.push_back(std::move(r));
   } else {
@@ -876,7 +917,10 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
                            std::to_string(2 * ps));
       for (int64_t i = 0; i < num_layers; ++i) {
         auto r = make_region("kv_" + std::to_string(i), aligned, ps);
-        if (backfill) backfill_all(*r);
+        if (backfill)
+          backfill_all(*r);
+        else
+          (void)prt_all(*r);
         layers_.push_back(std::move(r));
       }
     }
@@ -892,6 +936,11 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
 bool KvAllocator::kv_tensors_created() {
   std::lock_guard<std::mutex> g(mu_);
   return num_layers_ > 0;
+}
+
+bool KvAllocator::uses_prt() {
+  std::lock_guard<std::mutex> g(mu_);
+  return !layers_.empty() && layers_[0]->prt;
 }
 
 std::vector<void *> KvAllocator::region_bases() {
@@ -1002,7 +1051,12 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
     KvRegion &r = *s.region;
     if (r.mapped[s.index] != 3 || r.page_size != ps) continue;
     const int64_t t0 = now_ns();
-    vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
+    if (r.rest_direct() && vmm_direct_bo(r.handle[s.index])) {
+      if (rest_replace(r, s.index, 1) != 0) throw GpuError("putting a released slot back into its rest state failed");
+    } else {
+      vmm_unmap(r.base + s.index * ps, ps, r.handle[s.index]);
+      if (r.rest_direct() && rest_map(r, s.index, 1) != 0) KVC_LOG(LOG_ERROR, "putting slot %zu back into its rest state failed", s.index);
+    }
     if (vmm_extent_pages(r.handle[s.index]) > 1) // one page out of a larger mapping: see unmap_collect
       if (void *bo = vmm_direct_bo(r.handle[s.index])) (void)DrmVm::instance().refresh_mappings_of(bo, ps);
     stats().t_unmap += now_ns() - t0;
@@ -1150,14 +1204,16 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
       if (vmm_hip_registered() && !r.registered[s.index]) register_slot(r, s.index); // once per slot
-      if (r.backfilled && !(chunked && r.zx)) {
-        if (r.zx) {
-          StaleAfter mark;
-          if (DrmVm::instance().clear(va, ps) != 0) throw GpuError("dropping a zero alias failed");
+      if (r.rest_direct() && !chunked) { // (chunked: replaced run by run below)
+        if (DrmVm::instance().clear(va, ps) != 0) throw GpuError("dropping the rest mapping of a slot failed");
+        if (r.zx) { // a zero alias was a live translation (a PRT entry is not)
+          tlb_stale().store(true);
           zx_dirty = DrmVm::instance().find(r.zx_handle);
-        } else {
-          vmm_unmap(va, ps);
+          dirty_tlb = true;
+          need_epoch = ctx->next_flush_epoch();
         }
+      } else if (r.backfilled && !r.rest_direct()) {
+        vmm_unmap(va, ps);
         dirty_tlb = true; // the alias's translation is live
         need_epoch = ctx->next_flush_epoch();
       }
@@ -1168,7 +1224,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (imported) {
         import_index = next_import;
         ph = Phys{(*imported)[next_import++], 0};
-      } else if (chunked && (!r.backfilled || r.zx)) {
+      } else if (chunked && (!r.backfilled || r.rest_direct())) {
         fresh.push_back(s); // backed below, run by run: adjacent slots share one ioctl
         stats().t_unmap_alias += t1 - t0;
         continue;
@@ -1188,8 +1244,8 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
         needs_access = vmm_map(va, ps, h);
       } catch (...) {
         if (!imported) pool->release(ph);
-        if (r.zx)
-          (void)DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), va, ps, (s.index % r.zx_pages) * ps);
+        if (r.rest_direct())
+          (void)rest_map(r, s.index, 1); // (its rest mapping was cleared above)
         else if (r.backfilled && vmm_try_map(va, ps, r.zero_of(s.index)))
           (void)vmm_try_set_access(va, ps, ctx->dev());
         throw;
@@ -1253,11 +1309,13 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           const int64_t t2 = now_ns();
           char *va = r.base + fresh[i].index * ps;
           try {
-            if (r.zx) { // the slots show pages of the zero extent: pages take their place in the same ioctl
-              vmm_replace_pieces(va, ps, n, got[0].h);
-              zx_dirty = DrmVm::instance().find(r.zx_handle);
-              dirty_tlb = true;
-              need_epoch = ctx->next_flush_epoch();
+            if (r.rest_direct()) { // the slots carry their rest mapping: pages take its place in the same ioctl
+              vmm_replace_pieces(va, ps, n, got[0].h, /*live=*/r.zx);
+              if (r.zx) { // zero aliases were live translations: rewrite the split remainders, invalidate before use
+                zx_dirty = DrmVm::instance().find(r.zx_handle);
+                dirty_tlb = true;
+                need_epoch = ctx->next_flush_epoch();
+              } // (PRT entries are invalid ones: never cached, nothing owed - tools/prt_probe.cpp stage 4)
             } else {
               vmm_map_pieces(va, ps, n, got[0].h);
             }
@@ -1303,9 +1361,8 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     for (auto it = done.rbegin(); it != done.rend(); ++it) {
       KvRegion &r = *it->region;
       char *va = r.base + it->index * ps;
-      if (r.zx) { // back to its page of the zero extent, the page dropped in the same ioctl
-        StaleAfter mark;
-        (void)DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), va, ps, (it->index % r.zx_pages) * ps);
+      if (r.rest_direct()) { // back to its rest state, the page dropped in the same ioctl
+        (void)rest_replace(r, it->index, 1);
       } else {
         (void)vmm_try_unmap(va, ps, r.handle[it->index]);
       }
@@ -1316,7 +1373,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       else
         (void)vmm_try_release(r.handle[it->index]);
       r.mapped[it->index] = 0;
-      if (r.backfilled && !r.zx && vmm_try_map(va, ps, r.zero_of(it->index))) (void)vmm_try_set_access(va, ps, ctx->dev());
+      if (r.backfilled && !r.rest_direct() && vmm_try_map(va, ps, r.zero_of(it->index))) (void)vmm_try_set_access(va, ps, ctx->dev());
     }
     (void)hipGetLastError();
     try {
@@ -1372,13 +1429,13 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
   std::vector<uint8_t> cleared(slots.size(), 0);
-  { // compat mode, zero extent: a run of adjacent slots goes back to showing zeros with ONE ioctl - the pages of the
-    // zero extent replace whatever is mapped there (runs end at the extent's group boundaries: slot i shows page i % Z)
+  { // PRT / zero extent: a run of adjacent slots goes back to its rest state with ONE ioctl that replaces whatever is
+    // mapped there (zero extent: runs end at the extent's group boundaries - slot i shows page i % Z)
     std::vector<uint32_t> zorder;
     for (uint32_t i = 0; i < slots.size(); ++i) {
       const KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if (r.zx && (m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])) zorder.push_back(i); // (a page ROCr mapped is ROCr's to unmap)
+      if (r.rest_direct() && (m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])) zorder.push_back(i); // (a page ROCr mapped is ROCr's to unmap)
     }
     std::sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
       return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
@@ -1388,16 +1445,14 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       const size_t first = slots[zorder[i]].index;
       size_t j = i + 1, last = first;
       while (j < zorder.size() && slots[zorder[j]].region == &r &&
-             (slots[zorder[j]].index == last || (slots[zorder[j]].index == last + 1 && (last + 1) % r.zx_pages != 0))) {
+             (slots[zorder[j]].index == last || (slots[zorder[j]].index == last + 1 && (last + 1) % r.rest_group() != 0))) {
         last = slots[zorder[j]].index; // (a slot listed twice stays inside its run: logged as "not mapped" below)
         ++j;
       }
       const int64_t t0 = now_ns();
       {
-        StaleAfter mark;
-        const int rc = DrmVm::instance().replace(DrmVm::instance().find(r.zx_handle), r.base + first * ps, (last - first + 1) * ps,
-                                                 (first % r.zx_pages) * ps);
-        if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the zero extent) failed: ") + strerror(rc < 0 ? -rc : rc));
+        const int rc = rest_replace(r, first, last - first + 1);
+        if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the rest state) failed: ") + strerror(rc < 0 ? -rc : rc));
       }
       stats().t_unmap += now_ns() - t0;
       for (size_t k = i; k < j; ++k) cleared[zorder[k]] = 1;
@@ -1412,7 +1467,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     for (uint32_t i = 0; i < slots.size(); ++i) {
       const KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if ((m == 1 || m == 2) && !r.backfilled && vmm_direct_bo(r.handle[slots[i].index])) order.push_back(i);
+      if ((m == 1 || m == 2) && !r.backfilled && !r.rest_direct() && vmm_direct_bo(r.handle[slots[i].index])) order.push_back(i);
     }
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
       return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
@@ -1459,14 +1514,13 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     gone.emplace_back(&r, s.index);
     ++u.n;
     if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
-    if (r.zx) {
-      // Its zeros are back already (REPLACE above); the invalidation happens inside this call, like for any compat region:
+    if (r.rest_direct()) {
+      // Its rest state is back already (REPLACE above). In compat mode the invalidation happens inside this call:
       // "unbacked VA reads as zeros" holds from the moment unmap returns (an asynchronous invalidation would let a read
-      // that follows at once still see the old page - observable, so not done).
-      u.any_backfilled = true;
-      if (!cleared[si] && // unmapped through ROCr just now (a page imported that way): its page of the zero extent goes back
-          DrmVm::instance().map(DrmVm::instance().find(r.zx_handle), va, ps, (s.index % r.zx_pages) * ps) != 0)
-        KVC_LOG(LOG_ERROR, "putting slot %zu back on the zero extent failed", s.index);
+      // that follows at once still see the old page - observable, so not done); a lazy region's runs behind the call.
+      if (r.backfilled) u.any_backfilled = true;
+      if (!cleared[si] && rest_map(r, s.index, 1) != 0) // unmapped through ROCr just now (a page imported that way)
+        KVC_LOG(LOG_ERROR, "putting slot %zu back into its rest state failed", s.index);
     } else if (r.backfilled) { // put the shared zero page back (ftensor.cpp:135-136), access ranged per run
       u.any_backfilled = true;
       const int64_t tr = now_ns();

@@ -110,6 +110,7 @@ public:
   // The buffer of zeros behind the unbacked slots of compat-mode regions (drm backend): created and filled on first use,
   // `*pages` pages of `page_bytes`; 0 if it cannot be had (the caller aliases sharded zero pages through ROCr instead).
   phys_handle_t zero_extent(size_t page_bytes, size_t *pages);
+  size_t zero_extent_pages(size_t page_bytes); // of the one that exists (0: none was needed)
   // block id <-> token index glue (index_kernels.hip); ids are HOST arrays, everything else device memory
   void expand_block_ids(const int64_t *ids, size_t n, int64_t tpb, int64_t *out, hipStream_t s);
   void alloc_extend_indices(const int64_t *pre_lens, const int64_t *seq_lens, const int64_t *last_loc, size_t bs,
@@ -214,6 +215,12 @@ struct KvRegion {
   bool zx = false;
   phys_handle_t zx_handle = 0;
   size_t zx_pages = 0;
+  // drm backend, the default rest state of unbacked slots in BOTH modes: a PRT mapping with no buffer (DrmVm::map_prt) -
+  // reads return 0, writes are dropped, nothing faults, and backing a slot is invalid -> valid: no TLB invalidation on
+  // the map path. `backfilled` then only says whether an unmap invalidates inside the call (compat) or behind it (lazy).
+  bool prt = false;
+  bool rest_direct() const { return zx || prt; }                       // unbacked slots carry a DRM mapping of ours
+  size_t rest_group() const { return zx ? zx_pages : (size_t)-1; }     // a REPLACE back to the rest state must not cross this
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
   std::vector<uint64_t> stale_epoch;   // per slot: the TLB invalidation (GpuContext::next_flush_epoch) that covers its last unmap
@@ -254,6 +261,7 @@ public:
   bool map_to_kv_tensors(const offset_t *offsets, size_t n);
   bool unmap_from_kv_tensors(const offset_t *offsets, size_t n);
   std::vector<void *> region_bases(); // layer-major, K then V (compact_blocks' region table)
+  bool uses_prt();                    // unbacked slots of this group's regions are PRT mappings
 
   // async unmap (KVC_OPT_ASYNC_UNMAP): wait until every queued unmap of this allocator / of all allocators has
   // been carried out; bytes still queued (they count as free for this process)
@@ -274,6 +282,9 @@ private:
   std::unique_ptr<KvRegion> make_region(const std::string &name, size_t size, size_t page_size);
   void destroy_region(KvRegion &r);
   void backfill_all(KvRegion &r);
+  bool prt_all(KvRegion &r);                       // PRT behind every slot of the region (false: not available)
+  int rest_replace(KvRegion &r, size_t first, size_t n); // slots [first, first+n) back to their rest state in one ioctl, whatever is mapped there
+  int rest_map(KvRegion &r, size_t first, size_t n);     // the same over slots that hold nothing
   void register_slot(KvRegion &r, size_t slot);   // hybrid backend: make HIP aware of the slot's VA (once per slot)
   void unregister_slots(KvRegion &r);             // ... and take that back before the VA range is freed
   // `imported`: a peer's pages, one per slot, instead of pages from the pool; imported_consumed[i] is set for every

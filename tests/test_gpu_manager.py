@@ -201,6 +201,8 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
         # demonstrates - writes to memory nobody allocated land on shared zero memory and overwrite each other - holds here
         # too, with a different period: the reference aliases every unbacked page to ONE zero page; the drm backend shows
         # page i % z of one zero extent behind slot i (z = 64), the sharded fallback one zero page per 256 slots.
+        # With PRT (the drm backend's default) there is no memory at all behind unbacked VA: such writes are DROPPED and
+        # every read returns 0 - nothing is corrupted because nothing is stored.
         from kvcached_amd import capi
         z = capi.get_option(capi.OPT_ZERO_EXTENT_PAGES) or 1
         n_slots = k.numel() * dtype.itemsize // PAGE_SIZE
@@ -209,9 +211,12 @@ def test_zero_page_aliasing_without_alloc_and_private_pages_with_alloc(monkeypat
             k[1 + i * tpp] = torch.full((heads, dim), float(i), dtype=dtype, device=DEV)
         torch.cuda.synchronize()
         back = {i: float(k[1 + i * tpp][0][0]) for i in pages}
-        assert sum(1 for i, b in back.items() if b == float(i)) < len(pages), "aliasing not observed"
-        for i in pages:                                  # every slot sees the LAST write to its zero page
-            assert back[i] == float(max(j for j in pages if j % z == i % z)), (i, z, back[i])
+        assert sum(1 for i, b in back.items() if b == float(i)) < len(pages), "writes to unallocated memory were kept"
+        if capi.get_option(capi.OPT_PRT):
+            assert set(back.values()) == {0.0}
+        else:
+            for i in pages:                              # every slot sees the LAST write to its zero page
+                assert back[i] == float(max(j for j in pages if j % z == i % z)), (i, z, back[i])
 
         # with alloc(): unique physical pages
         blocks_per_page = PAGE_SIZE // (page_tokens * cell)

@@ -61,7 +61,9 @@ def test_unbacked_va_aliases_the_zero_page(vmm):
     k[5] = 1234                       # write through page 0's alias ...
     torch.cuda.synchronize()
     z = capi.get_option(capi.OPT_ZERO_EXTENT_PAGES)
-    if z:   # drm backend: slot i of every region shows page i % z of ONE zero extent - slot 0 of the next layer is the same memory
+    if capi.get_option(capi.OPT_PRT):   # drm backend: no page at all behind unbacked VA - the write was dropped, reads stay 0
+        assert int(k[5]) == 0 and int(k[3 * epp + 5]) == 0 and int(ts[1].view(torch.int16)[5]) == 0
+    elif z:  # zero extent: slot i of every region shows page i % z of ONE buffer - slot 0 of the next layer is the same memory
         assert int(ts[1].view(torch.int16)[5]) == 1234 and int(k[3 * epp + 5]) == 0
     else:   # sharded zero pages through ROCr: the slots of one shard are one physical page, like the reference's single one
         assert int(k[3 * epp + 5]) == 1234  # ... is visible through page 3's alias
@@ -113,7 +115,9 @@ _CONFIGS = [(b, mode, au, ck, "") for b in ("drm", "hybrid", "hip") for mode in 
 _CONFIGS += [("drm", mode, 0, 64, off) for mode in ("lazy", "compat")
              for off in ("KVCACHED_SCRUB_ON_RELEASE=false", "KVCACHED_KFD_TLB_FLUSH=false", "KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES=true",
                          "KVCACHED_ASYNC_SHOOTDOWN=false")]
-_CONFIGS += [("drm", "compat", 0, 64, "KVCACHED_ZERO_EXTENT=false"), ("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true")]
+_CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("drm", "lazy", 1, 64, "KVCACHED_PRT=false"),
+             ("drm", "lazy", 0, 64, "KVCACHED_PRT=false"), ("drm", "compat", 0, 64, "KVCACHED_PRT=false"),   # zero extent / unmapped VA
+             ("drm", "compat", 0, 1, "KVCACHED_PRT=false")]
 
 
 @pytest.mark.parametrize("backend,mode,async_unmap,extent_pages,switch", _CONFIGS)
@@ -131,6 +135,7 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
     if switch:
         monkeypatch.setenv(*switch.split("="))
     ops, capi, ts = _setup(vmm, layers=2, per_layer=64 * PAGE, backfill=(mode == "compat"), kv=1, unified=False)
+    assert capi.get_option(capi.OPT_PRT) == int(backend == "drm" and switch != "KVCACHED_PRT=false")
     want_backend = {"drm": 3, "hybrid": 2, "hip": 0}[backend]
     assert capi.get_option(108) == want_backend
     assert capi.get_option(capi.OPT_ASYNC_UNMAP) == async_unmap
@@ -151,9 +156,11 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
         torch.cuda.synchronize()
         victims = rng.sample(sorted(stamp), rng.randint(1, max(1, len(stamp) * 2 // 3)))
         assert ops.unmap_from_kv_tensors([i * PAGE for i in victims])
+        if capi.get_option(capi.OPT_PRT) and mode == "lazy":
+            capi.flush_unmaps()                                        # lazy: the invalidation runs behind the call
         for i in victims:
             stamp.pop(i)
-            if mode == "compat":
+            if mode == "compat" or capi.get_option(capi.OPT_PRT):      # (PRT: unbacked VA reads as zeros in lazy mode too)
                 for t in ts:
                     assert int(torch.count_nonzero(t[i * epp:(i + 1) * epp])) == 0, (rnd, i)
         for i, v in stamp.items():
