@@ -577,7 +577,7 @@ def main():
                     "lazy_mode_unmapped_va_instead_of_prt_round1": V(mode="lazy", env={"KVCACHED_PRT": "false"}),
                     "lazy_mode_map_waits_for_all_invalidations": V(mode="lazy", env={"KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES": "true"}),
                     "lazy_mode_fill_in_the_map_call": V(mode="lazy", env={"KVCACHED_SCRUB_ON_RELEASE": "false"}),
-                    "compat_sharded_zero_pages_through_rocr_round1": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false"}),
+                    "compat_sharded_zero_pages_through_rocr_round1": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false", "KVCACHED_PRT": "false"}),
                     "hybrid_backend_same_cycle": V(be="hybrid"),
                     "hip_backend_same_cycle": V(be="hip"),
                     "hip_backend_lazy": V(mode="lazy", be="hip"),

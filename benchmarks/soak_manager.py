@@ -33,11 +33,17 @@ def main():
     ap.add_argument("--pool-mb", type=int, default=None, help="KVCACHED_PHYS_POOL_MB (0: every whole extent goes straight back "
                     "to the driver, so that held/mapped shows fragmentation alone)")
     ap.add_argument("--extent-pages", type=int, default=None, help="KVCACHED_PHYS_CHUNK_PAGES")
+    ap.add_argument("--touch-unbacked", action="store_true",
+                    help="every 32 ops a kernel reads one word of EVERY slot of every region, backed or not (needs a mode in which "
+                         "unbacked VA does not fault: PRT or zero aliases): if a PRT 'miss' were ever cached by the GPU, a slot "
+                         "backed afterwards would be shadowed by it and its signatures would come back wrong")
     args = ap.parse_args()
     if args.pool_mb is not None:
         os.environ["KVCACHED_PHYS_POOL_MB"] = str(args.pool_mb)
     if args.extent_pages is not None:
         os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = str(args.extent_pages)
+    if args.touch_unbacked and not args.compat and os.environ.get("KVCACHED_PRT", "true").lower() in ("0", "false"):
+        raise SystemExit("--touch-unbacked needs PRT or --compat: unmapped VA faults")
     if args.backend:
         os.environ["KVCACHED_VMM_BACKEND"] = args.backend
     os.environ["KVCACHED_ASYNC_UNMAP"] = "true" if args.async_unmap else "false"
@@ -56,6 +62,7 @@ def main():
     vmm_ops.init_kvcached(dev, PAGE, False)
     backend = {0: "hip", 2: "hybrid", 3: "drm"}[capi.get_option(108)]
     max_extent_pages = int(capi.get_option(119)) if backend == "drm" and capi.get_option(110) else 1
+    capi_prt = 0
     blocks_per_page = PAGE // BLOCK_BYTES
     num_blocks = args.page_ids * blocks_per_page
     per_layer = num_blocks * BLOCK_BYTES * 2                   # K half + V half
@@ -64,6 +71,7 @@ def main():
     v_off = per_layer // 2 // 8
     m = kcm.KVCacheManager(num_blocks=num_blocks, block_size=BLOCK_TOKENS, cell_size=CELL, num_layers=LAYERS)
     assert m._post_init_done.wait(30)
+    capi_prt = capi.get_option(128)
     ipc = m.page_allocator._ipc_name()
     full_limit = per_layer * LAYERS
     rng = np.random.default_rng(args.seed)
@@ -127,6 +135,9 @@ def main():
     slots_per_page_id = LAYERS * 2
     footprint = []                                              # (pages held from the driver) / (pages mapped), sampled
     n_ops = 0
+    touched_sum = 0
+    if args.touch_unbacked:
+        assert capi.get_option(128) or args.compat, "unbacked VA would fault"
     t_progress = time.time()
     while time.time() < t_end and not bad:
         n_ops += 1
@@ -134,6 +145,10 @@ def main():
             t_progress = time.time()
             print(f"[soak] {int(t_end - time.time())} s to go, {counts['alloc']} allocs, {counts['blocks_verified']} blocks verified, "
                   f"{bad} wrong words", file=sys.stderr, flush=True)
+        if args.touch_unbacked and n_ops % 32 == 0:
+            for w in words:
+                touched_sum += int(w[::PAGE // 8].sum())              # one word per 2 MiB slot, K half and V half alike
+            counts["sweeps_over_every_slot"] = counts.get("sweeps_over_every_slot", 0) + 1
         if n_ops % 64 == 0:
             st_now = capi.get_stats()
             held_pages = st_now["handles_created"] - st_now["handles_released"]
@@ -187,7 +202,7 @@ def main():
     fp = sorted(footprint) or [0.0]
     out = dict(held_over_mapped={"p50": round(fp[len(fp) // 2], 3), "p90": round(fp[int(len(fp) * 0.9)], 3), "max": round(fp[-1], 3),
                                  "what": "physical pages held from the driver (mapped + pooled + free pieces of partly used chunks) per mapped page"},
-               max_extent_pages=max_extent_pages, pool_mb=os.environ.get("KVCACHED_PHYS_POOL_MB", "default (16384)"),
+               max_extent_pages=max_extent_pages, prt=bool(capi_prt), pool_mb=os.environ.get("KVCACHED_PHYS_POOL_MB", "default (16384)"),
                backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
                prealloc=args.prealloc, **counts, wrong_words=bad, inuse_pages_at_end=inuse,
                pages_mapped=st["pages_mapped"], pages_unmapped=st["pages_unmapped"],

@@ -71,13 +71,15 @@ int kvc_map_to_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 
 /* Runtime knobs (also read once from the environment at kvc_init):
- *   KVC_OPT_ZERO_BACKFILL  1 (default, as the reference does: csrc/ftensor.cpp:160-176) = every unbacked VA page shows
- *                              zeros: with the drm backend the pages of ONE zero extent, aliased a group of 64 slots per
- *                              ioctl (slot i shows its page i % 64), a run of slots going alias -> pages and back with
- *                              one REPLACE ioctl each; with the fallback backends sharded zero pages
- *                              through ROCr. 0 ("lazy", KVCACHED_ZERO_BACKFILL=false) = unbacked VA stays unmapped: a
- *                              stray access FAULTS instead of reading zeros, and no invalidation sits on the
- *                              allocation path (3x the rate).
+ *   KVC_OPT_ZERO_BACKFILL  1 (default, as the reference does: csrc/ftensor.cpp:160-176) = unbacked VA reads as zeros from
+ *                              the moment an unmap returns. 0 ("lazy", KVCACHED_ZERO_BACKFILL=false) = the TLB
+ *                              invalidation an unmap owes runs behind the call on a thread of the library.
+ *                              With the drm backend on gfx950 unbacked VA is a PRT mapping in BOTH modes (reads 0,
+ *                              writes dropped, no fault, no zero page, no invalidation on the map path: DESIGN.md
+ *                              §4.2; kvc_get_option(128)); where PRT is not to be had (KVCACHED_PRT=false, other
+ *                              GPUs, the fallback backends) mode 1 aliases zero pages (one zero extent on drm,
+ *                              sharded pages through ROCr otherwise) and mode 0 leaves unbacked VA unmapped - a
+ *                              stray access then FAULTS.
  *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
  *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
  *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py).

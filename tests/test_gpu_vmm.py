@@ -264,15 +264,23 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
 
 def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, monkeypatch):
     """Unmaps invalidate the TLBs (the VMM calls do not); maps need to only where something valid may still be cached:
-    a zero alias being replaced (compat mode) or an invalidation somebody deferred. Mapping an unbacked slot whose
+    a zero alias being replaced (compat mode WITHOUT PRT: a PRT entry is an invalid one) or an invalidation somebody
+    deferred. Mapping an unbacked slot whose
     last unmap was invalidated needs nothing - an invalid translation is never cached on GFX9+ (KFD itself flushes
     after unmap only on this GPU family; tools/drm_vmm_probe.cpp mode 3). Data check: pages recycled through the
     pool land on other slots between live neighbours and read zeros, neighbours keep their contents."""
     epp = PAGE // 2
-    for mode, per_map in (("lazy", 0), ("compat", 1), ("always", 1)):
+    for mode, per_map in (("lazy", 0), ("compat", 1), ("compat-zero-extent", 1), ("always", 1)):
         if mode == "always":
             monkeypatch.setenv("KVCACHED_MAP_SHOOTDOWN", "always")
+        if mode == "compat-zero-extent":
+            monkeypatch.setenv("KVCACHED_PRT", "false")
+            mode = "compat"
+        else:
+            monkeypatch.delenv("KVCACHED_PRT", raising=False)
         ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=(mode == "compat"), kv=1, unified=True)
+        if mode == "compat" and capi.get_option(capi.OPT_PRT):
+            per_map = 0                                                    # nothing valid is replaced: no invalidation on the map path
         t = ts[0]
         capi.reset_stats()
         even = [s * PAGE for s in range(0, 32, 2)]
