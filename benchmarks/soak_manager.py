@@ -44,6 +44,12 @@ def main():
         os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = str(args.extent_pages)
     if args.touch_unbacked and not args.compat and os.environ.get("KVCACHED_PRT", "true").lower() in ("0", "false"):
         raise SystemExit("--touch-unbacked needs PRT or --compat: unmapped VA faults")
+    if args.touch_unbacked and (args.prealloc or args.async_unmap):
+        # A slot IN TRANSITION is not at rest: inside the one ioctl that replaces PRT by a page (or back) the kernel first
+        # clears the range and then writes the new entries, and a GPU access that lands in that window faults (found the
+        # hard way: profiles/r02_soak_touch_unbacked_fault.log). Nothing legitimate touches a slot that is being backed or
+        # given up - but this sweep would, as soon as another thread of the library maps or unmaps in the background.
+        raise SystemExit("--touch-unbacked only without --prealloc / --async-unmap: it must not race with background (un)mapping")
     if args.backend:
         os.environ["KVCACHED_VMM_BACKEND"] = args.backend
     os.environ["KVCACHED_ASYNC_UNMAP"] = "true" if args.async_unmap else "false"
