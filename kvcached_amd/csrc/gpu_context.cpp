@@ -529,6 +529,13 @@ void GpuContext::flusher_loop() {
     if (fl_stop_) break;
     fl_kick_ = false;
     lk.unlock();
+    // The invalidation and the page-table ioctls of a map or unmap call serialise in the kernel (a REPLACE issued while
+    // the KFD pair is in flight waits for most of its 0.4 ms). Nobody is waiting for THIS invalidation - whoever needs
+    // one earlier performs it himself (ensure_flushed*) - so it yields to foreground calls: it starts once none has
+    // been active for 150 us, or after 2 ms at the latest (an engine that frees and allocates in one scheduler step
+    // gets its alloc through first; a tight loop is invalidated every few iterations instead of behind every one).
+    const int64_t t0 = now_ns();
+    while (foreground_busy() && now_ns() - t0 < 2000000) std::this_thread::sleep_for(std::chrono::microseconds(40));
     try {
       ensure_flushed();
     } catch (const std::exception &e) {

@@ -987,6 +987,7 @@ std::vector<KvAllocator::Slot> KvAllocator::slots_for(const offset_t *offsets, s
 
 bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
   const int64_t t0 = now_ns();
+  GpuContext::Foreground fg(ctx_);
   std::unique_lock<std::mutex> g(mu_, std::defer_lock);
   lock_foreground(g);
   if (num_layers_ == 0) {
@@ -1001,6 +1002,7 @@ bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
 
 bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
   const int64_t t0 = now_ns();
+  GpuContext::Foreground fg(ctx_);
   std::unique_lock<std::mutex> g(mu_, std::defer_lock);
   lock_foreground(g);
   if (num_layers_ == 0) {

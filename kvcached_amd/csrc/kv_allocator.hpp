@@ -145,6 +145,20 @@ public:
   // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
   // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
   void request_async_flush();
+  // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
+  struct Foreground {
+    GpuContext *c;
+    explicit Foreground(GpuContext *ctx) : c(ctx) {
+      if (c) c->fg_active_.fetch_add(1);
+    }
+    ~Foreground() {
+      if (c) {
+        c->fg_last_ns_.store(now_ns());
+        c->fg_active_.fetch_sub(1);
+      }
+    }
+  };
+  bool foreground_busy() const { return fg_active_.load() > 0 || now_ns() - fg_last_ns_.load() < 150000; }
 
 private:
   struct Timed {
@@ -160,6 +174,8 @@ private:
   hipStream_t stream_ = nullptr;
   std::mutex flush_mu_; // serialises TLB invalidations
   std::atomic<uint64_t> flush_started_{0}, flush_done_{0};
+  std::atomic<int> fg_active_{0};
+  std::atomic<int64_t> fg_last_ns_{0};
   std::thread flusher_;
   std::mutex fl_mu_;
   std::condition_variable fl_cv_;
