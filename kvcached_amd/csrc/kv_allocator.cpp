@@ -1431,13 +1431,16 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
   std::vector<uint8_t> cleared(slots.size(), 0);
+  const bool own_direct = xpool->multi_page(); // our own pages are direct DRM buffers (extent pools exist only on that path)
   { // PRT / zero extent: a run of adjacent slots goes back to its rest state with ONE ioctl that replaces whatever is
     // mapped there (zero extent: runs end at the extent's group boundaries - slot i shows page i % Z)
     std::vector<uint32_t> zorder;
     for (uint32_t i = 0; i < slots.size(); ++i) {
       const KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if (r.rest_direct() && (m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])) zorder.push_back(i); // (a page ROCr mapped is ROCr's to unmap)
+      // (a page ROCr mapped is ROCr's to unmap; our own pages of an extent pool are KFD buffers imported into DRM, all of them:
+      // no need to ask DrmVm about each one)
+      if (r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])))) zorder.push_back(i);
     }
     std::sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
       return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
@@ -1469,7 +1472,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     for (uint32_t i = 0; i < slots.size(); ++i) {
       const KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if ((m == 1 || m == 2) && !r.backfilled && !r.rest_direct() && vmm_direct_bo(r.handle[slots[i].index])) order.push_back(i);
+      if (!r.backfilled && !r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])))) order.push_back(i);
     }
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
       return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
@@ -1515,7 +1518,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     r.mapped[s.index] = 0;
     gone.emplace_back(&r, s.index);
     ++u.n;
-    if (own && xpool->multi_page() && vmm_extent_pages(r.handle[s.index]) > 1) touched.push_back(chunk_of(r.handle[s.index]));
+    if (own && own_direct && is_piece(r.handle[s.index])) touched.push_back(chunk_of(r.handle[s.index])); // (a tagged handle of our own pool: a page of a multi-page extent)
     if (r.rest_direct()) {
       // Its rest state is back already (REPLACE above). In compat mode the invalidation happens inside this call:
       // "unbacked VA reads as zeros" holds from the moment unmap returns (an asynchronous invalidation would let a read
@@ -1552,6 +1555,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   { // every driver call that removed or rewrote a translation has returned: the next invalidation to START covers them all
     const uint64_t epoch = ctx->next_flush_epoch();
     for (auto &g : gone) g.first->stale_epoch[g.second] = epoch;
+    u.epoch = epoch;
   }
 }
 
@@ -1576,9 +1580,11 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   //     caller's free() and, unless an alloc follows within that tick, reaches nobody's critical path
   //     (KVCACHED_ASYNC_SHOOTDOWN, on by default; one page id: free() 0.6 -> 0.2 ms).
   const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
-  if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer)
+  if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer) {
+    // (starting it on the context's thread and overlapping the scrub launch and the pool with it was tried: the thread
+    // hand-off costs what the overlap gains)
     ctx->ensure_flushed();
-  else if (options().defer_unmap_shootdown.load())
+  } else if (options().defer_unmap_shootdown.load())
     ctx->defer_tlb_shootdown(); // explicitly left to the next map batch / release to the driver
   else
     ctx->request_async_flush(); // this context's own thread does it now, off the caller's path

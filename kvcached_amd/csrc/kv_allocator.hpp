@@ -144,7 +144,8 @@ public:
   // Have this context's own thread do ensure_flushed() right away (started on first use): the unmap path's 0.3-0.5 ms
   // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
   // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
-  void request_async_flush();
+  // `urgent`: the caller will wait for it (ensure_flushed_through) at the end of what he is doing - start at once
+  void request_async_flush(bool urgent = false);
   // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
   struct Foreground {
     GpuContext *c;
@@ -179,7 +180,7 @@ private:
   std::thread flusher_;
   std::mutex fl_mu_;
   std::condition_variable fl_cv_;
-  bool fl_stop_ = false, fl_kick_ = false;
+  bool fl_stop_ = false, fl_kick_ = false, fl_urgent_ = false;
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
@@ -313,6 +314,7 @@ private:
     std::vector<Phys> own;
     std::vector<phys_handle_t> imported;
     bool any_backfilled = false;
+    uint64_t epoch = 0; // the invalidation that covers these unmaps (GpuContext::next_flush_epoch after the driver calls)
     int64_t n = 0;
     size_t page_size = 0;
   };
