@@ -66,6 +66,13 @@ def parse_args():
     return ap.parse_args()
 
 
+# host time of the two calls by segment (read-only options 130 + i of the library)
+HOST_SEGMENTS = {0: "map: offsets to slots", 1: "map: classify slots", 2: "map: sort into runs", 3: "map: pool", 4: "map: page-table ioctls",
+                 5: "map: per-run bookkeeping", 6: "map: invalidation owed", 7: "map: wait for own fill", 8: "map: wait for the scrub of these pages", 9: "map: scrubs behind the newest (count, x1000)", 10: "unmap: offsets to slots", 11: "unmap: sort into runs",
+                 12: "unmap: page-table ioctls", 13: "unmap: per-slot bookkeeping", 14: "unmap: remainders of split mappings",
+                 15: "unmap: epochs", 16: "unmap: TLB invalidation", 17: "unmap: scrub launch", 18: "unmap: pool"}
+
+
 def batch_offsets(batch_index: int, seed: int = 0, slot: int = PAGE):
     """Offsets of one 2 GiB batch: 1024 shuffled 2 MiB slots (or 2 GiB / slot compound slots)."""
     import numpy as np
@@ -152,9 +159,14 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         if sync:
             sync()
         per_map, per_unmap = [], []
+        # the inputs of the timed steps are ready before the clock starts: the offsets of every batch, already in the form
+        # the boundary takes them in (an int64 array for the C ABI; the TP fan-out pickles Python lists)
+        ready = [batch_offsets((warmup + i) % window, slot=slot) for i in range(steps)]
+        if fanout is None:
+            ready = [capi.i64_array(o) for o in ready]
         t0 = time.perf_counter()
         for i in range(steps):
-            offs = batch_offsets((warmup + i) % window, slot=slot)
+            offs = ready[i]
             ta = time.perf_counter()
             mapper(offs)
             tb = time.perf_counter()
@@ -175,6 +187,7 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
                          "kfd_export_us": round((c1[1] - c0[1]) / n_created / 1e3, 2),
                          "drm_import_us": round((c1[2] - c0[2]) / n_created / 1e3, 2)} if n_created else None)
         st["driver_ns"] = capi.get_driver_breakdown()
+        st["host_segments_ns"] = {name: int(capi.get_option(130 + i)) for i, name in HOST_SEGMENTS.items()}
         capi.set_option(capi.OPT_PROFILE, 0)
         if burst:  # give everything back, outside the timed region
             for i in range(steps):
@@ -207,6 +220,7 @@ def summarize(res, steps, n_gpus=1):
         "va_reserve_and_backfill_s": res["reserve_s"],
         "driver_us_per_page": {k: round(v / 1e3 / (steps * BATCH_PAGES), 2) for k, v in st.get("driver_ns", {}).items() if v},
         "tlb_shootdown_us": round(st["shootdown_ns"] / 1e3 / max(1, st["tlb_shootdowns"]), 1),
+        "host_us_per_call": {k: round(v / 1e3 / steps, 1) for k, v in st.get("host_segments_ns", {}).items() if v},
     }
     return out
 
@@ -539,7 +553,8 @@ def main():
             "ranks": ranks_seen,
             "config": {"workload": "bench_vmm: 64 GiB VA window (one untimed warm-up sweep over the window during set-up, as in "
                                    "the protocol); step = map+zero then unmap one batch of 1024 x 2 MiB "
-                                   "pages (shuffled offsets), both halves timed. Physical pages are recycled through the "
+                                   "pages (shuffled offsets), both halves timed; the offset arrays of the timed steps are made before "
+                                   "the clock starts. Physical pages are recycled through the "
                                    "library's pool: the timed steps create none (handles_created) - allocation from the driver "
                                    "is what growth_burst_* measure",
                        "kfd_create": res["kfd_create"], "kfd_tlb_flush": res["kfd_tlb_flush"], "max_extent_pages": res["max_extent_pages"],
@@ -556,6 +571,7 @@ def main():
             "handles_created": main_sum["handles_created"], "handles_reused": main_sum["handles_reused"],
             "va_reserve_and_backfill_s": round(main_sum["va_reserve_and_backfill_s"], 3),
             "driver_us_per_page": main_sum["driver_us_per_page"], "tlb_shootdown_us": main_sum["tlb_shootdown_us"],
+            "host_us_per_call": main_sum["host_us_per_call"],
             "roofline": roofline_from(res["stats"]),
         }
         if world == 1 and not rehearsal:

@@ -179,11 +179,14 @@ def create_kv_tensors(size: int, dtype_size: int, dev: str, num_layers: int, num
 
 
 def map_to_kv_tensors(offsets: Sequence[int], group_id: int = 0) -> None:
-    check(lib.kvc_map_to_kv_tensors(i64_array(offsets), len(offsets), group_id))
+    """`offsets`: a sequence of ints, or an int64 ctypes array made ahead of time (i64_array) - handed over as it is."""
+    arr = offsets if isinstance(offsets, ctypes.Array) else i64_array(offsets)
+    check(lib.kvc_map_to_kv_tensors(arr, len(offsets), group_id))
 
 
 def unmap_from_kv_tensors(offsets: Sequence[int], group_id: int = 0) -> None:
-    check(lib.kvc_unmap_from_kv_tensors(i64_array(offsets), len(offsets), group_id))
+    arr = offsets if isinstance(offsets, ctypes.Array) else i64_array(offsets)
+    check(lib.kvc_unmap_from_kv_tensors(arr, len(offsets), group_id))
 
 
 def set_option(opt: int, value: int) -> None:

@@ -158,6 +158,13 @@ int64_t kvc_get_option(int opt) {
   case 115: return DrmVm::instance().create_times().count.load();
   case 116: return DrmVm::instance().create_times().free_ns.load();   // DRM + KFD frees
   case 117: return DrmVm::instance().create_times().frees.load();
+  // 130..149: host nanoseconds of the map / unmap calls by segment since the last reset (read-only diagnostics).
+  // map: 130 offsets -> slots, 131 classify, 132 sort into runs, 133 pool, 134 page-table ioctls, 135 per-run bookkeeping,
+  // 136 invalidation owed, 137 wait for own fill, 138 wait for the scrub of these pages, 139 (a count: scrubs behind the newest); unmap: 140 offsets -> slots, 141 runs, 142 page-table ioctls, 143 per-slot bookkeeping,
+  // 144 remainders, 145 epochs, 146 invalidation, 147 scrub launch, 148 pool
+  case 130: case 131: case 132: case 133: case 134: case 135: case 136: case 137: case 138: case 139:
+  case 140: case 141: case 142: case 143: case 144: case 145: case 146: case 147: case 148: case 149:
+    return stats().seg[opt - 130];
   case 118: { // the direct KFD TLB flush is what tlb_shootdown() uses (read-only)
     GpuContext *ctx = KvAllocator::gpu();
     return ctx && ctx->kfd_flush_active() ? 1 : 0;

@@ -56,6 +56,36 @@ inline phys_handle_t chunk_of(phys_handle_t h) { return is_piece(h) ? (h & ((1ul
 inline unsigned piece_of(phys_handle_t h) { return is_piece(h) ? static_cast<unsigned>((h >> kPieceShift) & 0x7f) : 0; }
 inline unsigned pages_of(phys_handle_t h) { return is_piece(h) ? static_cast<unsigned>((h >> kPagesShift) & 0xff) + 1 : 1; }
 
+// Groups a batch of keys without sorting it (a batch of 1024 pages names a few dozen extents in any order): open addressing
+// over a table of indices into the list of groups, which keeps the order of first appearance.
+template <class V> class KeyGroups {
+public:
+  explicit KeyGroups(size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    slot_.assign(cap, kNone);
+    mask_ = cap - 1;
+    items_.reserve(std::min<size_t>(n, 64));
+  }
+  V &at(uint64_t key) {
+    if (last_ != kNone && items_[last_].first == key) return items_[last_].second;
+    size_t i = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & mask_;
+    for (; slot_[i] != kNone; i = (i + 1) & mask_)
+      if (items_[slot_[i]].first == key) return items_[last_ = slot_[i]].second;
+    slot_[i] = last_ = (uint32_t)items_.size();
+    items_.emplace_back(key, V{});
+    return items_.back().second;
+  }
+  std::vector<std::pair<uint64_t, V>> &items() { return items_; }
+
+private:
+  static constexpr uint32_t kNone = 0xffffffffu;
+  std::vector<uint32_t> slot_;
+  std::vector<std::pair<uint64_t, V>> items_;
+  size_t mask_ = 0;
+  uint32_t last_ = kNone;
+};
+
 struct VmmCounters { // in pages
   std::atomic<int64_t> created{0}, released{0}, reused{0};
 };
@@ -150,6 +180,7 @@ public:
     held_pages_ += n;
     ctr_->created += n;
     last_created_pages_ = n;
+    ++creations_;
     return take_pieces_locked(h, e, 0, n, out, recycled);
   }
 
@@ -174,26 +205,29 @@ public:
     if (n == 0) return;
     std::vector<Victim> victims;
     const bool pressure = drv_.under_pressure && drv_.under_pressure();
+    // pieces of one extent are handled together (one lookup, one re-bucketing): a batch lists a few dozen extents
+    struct Group {
+      uint64_t bits = 0;
+      uint32_t cnt = 0;
+      bool twice = false;
+    };
+    KeyGroups<Group> groups(n);
+    for (size_t i = 0; i < n; ++i) {
+      Group &g = groups.at(key_of(ps[i].h));
+      const unsigned idx = idx_of(ps[i].h);
+      const uint64_t bit = idx < 64 ? 1ull << idx : 0;
+      g.twice = g.twice || bit == 0 || (g.bits & bit);
+      g.bits |= bit;
+      ++g.cnt;
+    }
     {
       std::lock_guard<std::mutex> g(mu_);
-      // pieces of one extent are handled together (one lookup, one re-bucketing): a batch lists a few dozen extents
-      std::vector<std::pair<phys_handle_t, unsigned>> order(n);
-      for (size_t i = 0; i < n; ++i) order[i] = {key_of(ps[i].h), idx_of(ps[i].h)};
-      std::sort(order.begin(), order.end());
-      for (size_t i = 0; i < n;) {
-        const phys_handle_t h = order[i].first;
-        size_t j = i;
-        uint64_t bits = 0;
-        bool twice = false;
-        for (; j < n && order[j].first == h; ++j) {
-          const uint64_t bit = order[j].second < 64 ? 1ull << order[j].second : 0;
-          twice = twice || bit == 0 || (bits & bit);
-          bits |= bit;
-        }
-        const size_t cnt = j - i;
-        i = j;
+      for (auto &kv : groups.items()) {
+        const phys_handle_t h = kv.first;
+        const uint64_t bits = kv.second.bits;
+        const size_t cnt = kv.second.cnt;
         auto it = tracked_.find(h);
-        if (it == tracked_.end() || twice || (bits & it->second.free_mask) || (bits & ~full_mask(it->second.n))) {
+        if (it == tracked_.end() || kv.second.twice || (bits & it->second.free_mask) || (bits & ~full_mask(it->second.n))) {
           bad_releases_ += cnt; // pieces of an unknown extent, listed twice, or not out: never corrupt the masks
           continue;
         }
@@ -318,6 +352,7 @@ public:
   }
 
   // ---- accounting
+  size_t creations() const { return creations_.load(); }
   size_t idle_pages() {
     std::lock_guard<std::mutex> g(mu_);
     return idle_pages_;
@@ -512,6 +547,7 @@ private:
   std::mutex mu_;
   uint64_t next_seq_ = 0, idle_stamp_ = 0;
   unsigned last_created_pages_ = 1;
+  std::atomic<size_t> creations_{0}; // extents created on demand (not for the reserve)
   size_t handed_out_since_clamp_ = 0;
   size_t recover_pages_ = 4096; // 8 GiB of 2 MiB pages handed out between two steps back up
   size_t held_pages_ = 0;   // everything obtained from the driver and not given back

@@ -29,6 +29,7 @@ void Stats::reset() {
   pages_scrubbed = pages_prescrubbed = 0;
   t_unmap_alias = t_acquire = t_map = t_access = t_unmap = t_release = t_realias = t_sync = 0;
   vmm.created = vmm.released = vmm.reused = 0;
+  for (auto &x : seg) x = 0;
   std::lock_guard<std::mutex> g(mu);
   fill_ms = compact_ms = 0;
 }
@@ -91,6 +92,8 @@ GpuContext::~GpuContext() {
   for (auto &a : arenas_) (void)hipMemAddressFree(a.base, a.size);
   arenas_.clear();
   if (scrub_stream_) (void)hipStreamDestroy(scrub_stream_);
+  for (auto &e : scrub_events_) (void)hipEventDestroy(e.second);
+  for (auto ev : scrub_free_events_) (void)hipEventDestroy(ev);
   kfd_flush_.close();
   if (uniq_bitmap_) (void)hipFree(uniq_bitmap_);
   if (uniq_header_) (void)hipFree(uniq_header_);
@@ -296,15 +299,61 @@ uint64_t GpuContext::scrub(const uint64_t *alias_addrs, size_t n, size_t page_by
   bind();
   zero_fill(ptrs.data(), ptrs.size(), page_bytes, scrub_stream_);
   stats().pages_scrubbed += (int64_t)ptrs.size();
-  return scrub_issued_.fetch_add(1) + 1;
+  const uint64_t ticket = scrub_issued_.fetch_add(1) + 1;
+  // an event behind every scrub: whoever gets these pages next waits for THIS scrub, not for the ones queued after it
+  // (the pool hands out the pages that have been idle longest: as a rule their scrub is long over and the wait is a query)
+  while (!scrub_events_.empty() && hipEventQuery(scrub_events_.front().second) == hipSuccess) retire_scrubs_locked(scrub_events_.front().first);
+  (void)hipGetLastError();
+  hipEvent_t ev = nullptr;
+  if (!scrub_free_events_.empty()) {
+    ev = scrub_free_events_.back();
+    scrub_free_events_.pop_back();
+  } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    ev = nullptr;
+  }
+  if (ev && hipEventRecord(ev, scrub_stream_) == hipSuccess) {
+    scrub_events_.emplace_back(ticket, ev);
+  } else { // no event: wait_scrub falls back to the whole stream
+    (void)hipGetLastError();
+    if (ev) scrub_free_events_.push_back(ev);
+  }
+  return ticket;
+}
+
+void GpuContext::retire_scrubs_locked(uint64_t through) {
+  while (!scrub_events_.empty() && scrub_events_.front().first <= through) {
+    scrub_free_events_.push_back(scrub_events_.front().second);
+    scrub_events_.pop_front();
+  }
+  uint64_t cur = scrub_done_.load();
+  while (cur < through && !scrub_done_.compare_exchange_weak(cur, through)) {
+  }
 }
 
 void GpuContext::wait_scrub(uint64_t ticket) {
   if (!ticket || scrub_done_.load() >= ticket) return;
-  const uint64_t covered = scrub_issued_.load(); // every scrub launched so far is ahead of the sync below
-  HIP_CHECK(hipStreamSynchronize(scrub_stream_));
-  uint64_t cur = scrub_done_.load();
-  while (cur < covered && !scrub_done_.compare_exchange_weak(cur, covered)) {
+  hipEvent_t ev = nullptr;
+  uint64_t covers = 0;
+  {
+    std::lock_guard<std::mutex> g(scrub_mu_);
+    if (scrub_done_.load() >= ticket) return;
+    for (auto &e : scrub_events_) // the first scrub at or behind `ticket` that still has its event (stream order: it covers `ticket`)
+      if (e.first >= ticket) {
+        ev = e.second;
+        covers = e.first; // once it has fired, everything up to it is over
+        break;
+      }
+  }
+  if (ev) {
+    HIP_CHECK(hipEventSynchronize(ev)); // (should the event be recycled meanwhile, this waits for a later scrub: longer, never shorter)
+    std::lock_guard<std::mutex> g(scrub_mu_);
+    retire_scrubs_locked(covers);
+  } else { // no event behind it (creation failed, or a ticket from before the events): the whole stream
+    const uint64_t covered = scrub_issued_.load(); // every scrub launched so far is ahead of the sync below
+    HIP_CHECK(hipStreamSynchronize(scrub_stream_));
+    std::lock_guard<std::mutex> g(scrub_mu_);
+    retire_scrubs_locked(covered);
   }
   harvest();
 }

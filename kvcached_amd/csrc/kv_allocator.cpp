@@ -1,5 +1,6 @@
 // kv_allocator.cpp — see kv_allocator.hpp.
 #include "kv_allocator.hpp"
+#include "run_scan.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -378,7 +379,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().clear_run_slots = std::max<int64_t>(0, env_i64("KVCACHED_DRM_CLEAR_RUN", 16));
   options().phys_chunk_pages = std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_PHYS_CHUNK_PAGES", 64)));
   options().extent_waste_pct = std::min<int64_t>(100, std::max<int64_t>(0, env_i64("KVCACHED_EXTENT_WASTE_PCT", 5)));
-  options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 1024)) << 20;
+  options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 2048)) << 20;
   options().scrub_on_release = env_bool("KVCACHED_SCRUB_ON_RELEASE", true) ? 1 : 0;
   options().map_waits_for_all_flushes = env_bool("KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES", false) ? 1 : 0;
   {
@@ -624,6 +625,7 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
   r->seq.assign(r->num_slots(), 0);
   r->stale_epoch.assign(r->num_slots(), 0);
   r->mapped.assign(r->num_slots(), 0);
+  r->mark.assign((r->num_slots() + 63) / 64, 0);
   r->registered.assign(r->num_slots(), 0);
   r->reg_group = std::max<size_t>(1, (size_t)std::max<int64_t>(0, options().hip_reg_group_mb.load()) * (1u << 20) / r->page_size);
   return r;
@@ -994,7 +996,10 @@ bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
     KVC_LOG(LOG_ERROR, "try to map to KV tensors when KV tensors are not created");
     return false;
   }
-  map_slots(slots_for(offsets, n), nullptr);
+  SegTimer sg;
+  const auto slots = slots_for(offsets, n);
+  sg.mark(0);
+  map_slots(slots, nullptr);
   stats().map_calls++;
   stats().map_ns += now_ns() - t0;
   return true;
@@ -1009,7 +1014,9 @@ bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
     KVC_LOG(LOG_ERROR, "try to unmap from KV tensors when KV tensors are not created");
     return false;
   }
+  SegTimer sg;
   auto slots = slots_for(offsets, n);
+  sg.mark(10);
   bool async = options().async_unmap.load() != 0; // also on the cpu device: same queue and thread, no driver calls
   for (auto &r : layers_) async = async && !r->backfilled; // compat mode promises zeros behind an unmap: stay synchronous
   if (async) {
@@ -1072,6 +1079,9 @@ bool KvAllocator::steal_pending(size_t ps, Phys *out) {
   return false;
 }
 
+using SlotRun = SlotRunOf<KvRegion>;
+using RunScan = RunScanOf<KvRegion>;
+
 // The hot loop. Per slot: [register with HIP, once per 64 MiB group] -> [unmap the zero alias] -> pooled handle -> map
 // (drm backend: one GEM_VA ioctl; else map + one set_access per contiguous run); zero_fill_pages launches that run on
 // the GPU while the host keeps issuing driver calls for the next slots (3/4 of the batch, then the rest); a TLB
@@ -1101,6 +1111,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   ExtentPool *pool = ctx->extents(ps, exportable_);
+  const bool cold = pool->creations() == 0;
   const bool fill = options().zero_fill.load() && !imported;
   const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
 
@@ -1186,10 +1197,22 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // Run-sized extents (KVCACHED_PHYS_CHUNK_PAGES > 1, drm backend): the unbacked slots of the batch are collected
   // first and then backed run by run - adjacent slots get adjacent pages of one buffer and ONE map ioctl.
   const bool chunked = pool->multi_page() && !imported;
-  std::vector<Slot> fresh;
+  RunScan fresh;
+  const bool hip_reg = vmm_hip_registered();
+  SegTimer sg;
   try {
     for (auto &s : slots) {
       KvRegion &r = *s.region;
+      if (chunked && r.mapped[s.index] == 0 && (!r.backfilled || r.rest_direct())) { // the common case, nothing per slot but a bit
+        if (hip_reg && !r.registered[s.index]) {
+          const int64_t t0 = now_ns();
+          register_slot(r, s.index); // once per slot
+          stats().t_unmap_alias += now_ns() - t0;
+        }
+        // the same slot listed twice in one call: the reference logs "already mapped" for the second and goes on (ftensor.cpp:104-107)
+        if (!fresh.add(&r, s.index)) KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", s.index);
+        continue; // backed below, run by run: adjacent slots share one ioctl
+      }
       if (r.mapped[s.index] == 3 && !imported) {
         r.mapped[s.index] = 1; // its queue entry is dropped by the reclaimer (state no longer 3)
         kept.push_back(s);
@@ -1205,7 +1228,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       }
       char *va = r.base + s.index * ps;
       int64_t t0 = now_ns();
-      if (vmm_hip_registered() && !r.registered[s.index]) register_slot(r, s.index); // once per slot
+      if (hip_reg && !r.registered[s.index]) register_slot(r, s.index); // once per slot
       if (r.rest_direct() && !chunked) { // (chunked: replaced run by run below)
         if (DrmVm::instance().clear(va, ps) != 0) throw GpuError("dropping the rest mapping of a slot failed");
         if (r.zx) { // a zero alias was a live translation (a PRT entry is not)
@@ -1226,10 +1249,6 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (imported) {
         import_index = next_import;
         ph = Phys{(*imported)[next_import++], 0};
-      } else if (chunked && (!r.backfilled || r.rest_direct())) {
-        fresh.push_back(s); // backed below, run by run: adjacent slots share one ioctl
-        stats().t_unmap_alias += t1 - t0;
-        continue;
       } else if (pool->acquire_run(1, &ph, &recycled, false) == 1) {
         recycled = true;
       } else if (steal_pending(ps, &ph)) { // async unmap: take the page of a released slot instead of creating one
@@ -1281,35 +1300,27 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       run_pages.push_back(va);
     }
     flush_run();
-    if (!fresh.empty()) {
-      std::sort(fresh.begin(), fresh.end(), [](const Slot &a, const Slot &b) {
-        return a.region != b.region ? a.region < b.region : a.index < b.index;
-      });
-      // the same slot listed twice in one call: the reference logs "already mapped" for the second and goes on (ftensor.cpp:104-107)
-      for (size_t i = 1; i < fresh.size();) {
-        if (fresh[i].region == fresh[i - 1].region && fresh[i].index == fresh[i - 1].index) {
-          KVC_LOG(LOG_ERROR, "Page %zu is already mapped.", fresh[i].index);
-          fresh.erase(fresh.begin() + (long)i);
-        } else {
-          ++i;
-        }
-      }
+    sg.mark(1);
+    if (fresh.size()) {
       std::vector<Phys> got(kMaxExtentPages);
-      for (size_t i = 0; i < fresh.size();) {
-        size_t j = i + 1;
-        while (j < fresh.size() && fresh[j].region == fresh[i].region && fresh[j].index == fresh[j - 1].index + 1) ++j;
-        while (i < j) { // slots [i, j) are neighbours: as many as one chunk can serve at a time
-          KvRegion &r = *fresh[i].region;
+      const std::vector<SlotRun> runs = fresh.collect();
+      sg.mark(2);
+      for (const SlotRun &run : runs) {
+        KvRegion &r = *run.r;
+        for (size_t at = run.first, end = run.first + run.count; at < end;) { // as many neighbours as one extent can serve at a time
           const int64_t t1 = now_ns();
           bool recycled = false;
-          size_t n = pool->acquire_run(j - i, got.data(), &recycled, false);
+          size_t prescrubbed = 0;
+          sg.mark(5);
+          size_t n = pool->acquire_run(end - at, got.data(), &recycled, false);
           if (n == 0 && steal_pending(ps, &got[0])) {
             n = 1; // (its unmap has set tlb_stale: flushed before the fill)
             need_epoch = ctx->next_flush_epoch();
           }
-          if (n == 0) n = pool->acquire_run(j - i, got.data(), &recycled, true);
+          if (n == 0) n = pool->acquire_run(end - at, got.data(), &recycled, true);
           const int64_t t2 = now_ns();
-          char *va = r.base + fresh[i].index * ps;
+          sg.mark(3);
+          char *va = r.base + at * ps;
           try {
             if (r.rest_direct()) { // the slots carry their rest mapping: pages take its place in the same ioctl
               vmm_replace_pieces(va, ps, n, got[0].h, /*live=*/r.zx);
@@ -1327,32 +1338,39 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           }
           stats().t_acquire += t2 - t1;
           stats().t_map += now_ns() - t2;
+          sg.mark(4);
           for (size_t k = 0; k < n; ++k) {
-            const Slot &s = fresh[i + k];
-            r.handle[s.index] = got[k].h;
-            r.seq[s.index] = got[k].seq;
-            r.mapped[s.index] = 1;
-            done.push_back(s);
+            const size_t index = at + k;
+            r.handle[index] = got[k].h;
+            r.seq[index] = got[k].seq;
+            r.mapped[index] = 1;
+            done.push_back(Slot{&r, index});
             max_ticket = std::max(max_ticket, got[k].wait_ticket);
             if (fill && got[k].scrub_ticket) {
               max_ticket = std::max(max_ticket, got[k].scrub_ticket);
-              stats().pages_prescrubbed++;
+              ++prescrubbed;
             } else if (fill)
-              pending.push_back(r.base + s.index * ps);
+              pending.push_back(r.base + index * ps);
           }
+          if (prescrubbed) stats().pages_prescrubbed += (int64_t)prescrubbed;
           if (always_flush) dirty_tlb = true;
           if (fill) launch_pending(false);
-          i += n;
+          at += n;
         }
       }
     }
+    sg.mark(5);
     if (fill) launch_pending(true);
     if (always_flush && dirty_tlb) tlb_stale().store(true);
     flush_for_batch(); // nothing may reach the new mappings through a stale translation of their own addresses
+    sg.mark(6);
     const int64_t ts = now_ns();
     if (launched) ctx->sync(nullptr);
+    sg.mark(7);
     ctx->wait_scrub(max_ticket);
     stats().t_sync += now_ns() - ts;
+    sg.mark(8);
+    if (max_ticket) stats().seg[9] += (int64_t)(ctx->scrubs_issued() - max_ticket); // (diagnostics: how many scrubs behind the newest the one waited for was)
   } catch (...) {
     // leave the regions as they were before this call; PageAllocator rolls the page ids back
     if (launched) (void)hipStreamSynchronize(ctx->stream());
@@ -1385,6 +1403,14 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     throw;
   }
   stats().pages_mapped += (int64_t)(done.size() + kept.size());
+  // Cold start: the first extents this pool ever had to create bring the reserve along, sized like themselves
+  // (KVCACHED_PHYS_RESERVE_MB): pages that come back are zeroed behind the unmap, and a free()+alloc()
+  // cycle that can draw on an idle batch never waits for that fill. One-off, here rather than on the watcher's next
+  // ticks so that it does not depend on a thread being around (a bare C-ABI caller has none); the watcher keeps it up.
+  if (cold && pool->creations() > 0 && !imported && !exportable_) { // (the reserve belongs to the engine's own pool, not to the exportable twin)
+    const size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / ps;
+    if (want) (void)pool->refill_reserve(want, want);
+  }
 }
 
 void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
@@ -1424,46 +1450,42 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   // out splits that mapping, and what is left of it must be rewritten (DrmVm::refresh_mappings_of) before the TLBs are
   // invalidated. An extent that loses ALL its mapped pages in this batch leaves nothing behind to rewrite.
   ExtentPool *xpool = ctx->extents(ps, exportable_);
-  std::vector<phys_handle_t> touched;
+  KeyGroups<uint32_t> touched(slots.size()); // extent -> pieces of it that this batch takes back
   std::vector<std::pair<KvRegion *, size_t>> gone;
   gone.reserve(slots.size());
   // drm backend, lazy regions: slots of this batch that are neighbours in VA go in runs - one CLEAR ioctl per run of up
   // to `clear_run_slots` instead of one UNMAP per slot (whatever the order the caller listed them in). Everything
   // inside such a run is a direct mapping of a page this very call gives up, so "drop all mappings in the range" is exact.
   std::vector<uint8_t> cleared(slots.size(), 0);
+  SegTimer sg;
   const bool own_direct = xpool->multi_page(); // our own pages are direct DRM buffers (extent pools exist only on that path)
   { // PRT / zero extent: a run of adjacent slots goes back to its rest state with ONE ioctl that replaces whatever is
     // mapped there (zero extent: runs end at the extent's group boundaries - slot i shows page i % Z)
-    std::vector<uint32_t> zorder;
+    RunScan scan;
     for (uint32_t i = 0; i < slots.size(); ++i) {
-      const KvRegion &r = *slots[i].region;
+      KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
       // (a page ROCr mapped is ROCr's to unmap; our own pages of an extent pool are KFD buffers imported into DRM, all of them:
-      // no need to ask DrmVm about each one)
-      if (r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])))) zorder.push_back(i);
+      // no need to ask DrmVm about each one. A slot listed twice: the second mention is logged as "not mapped" below)
+      if (r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index]))))
+        if (scan.add(&r, slots[i].index)) cleared[i] = 2; // (2: and its extent is counted in `touched` with its run)
     }
-    std::sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
-      return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
-    });
-    for (size_t i = 0; i < zorder.size();) {
-      KvRegion &r = *slots[zorder[i]].region;
-      const size_t first = slots[zorder[i]].index;
-      size_t j = i + 1, last = first;
-      while (j < zorder.size() && slots[zorder[j]].region == &r &&
-             (slots[zorder[j]].index == last || (slots[zorder[j]].index == last + 1 && (last + 1) % r.rest_group() != 0))) {
-        last = slots[zorder[j]].index; // (a slot listed twice stays inside its run: logged as "not mapped" below)
-        ++j;
-      }
+    const std::vector<SlotRun> runs = scan.collect([](const KvRegion &r) { return r.rest_group(); });
+    sg.mark(11);
+    for (const SlotRun &run : runs) {
       const int64_t t0 = now_ns();
-      {
-        const int rc = rest_replace(r, first, last - first + 1);
-        if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the rest state) failed: ") + strerror(rc < 0 ? -rc : rc));
-      }
+      const int rc = rest_replace(*run.r, run.first, run.count);
+      if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the rest state) failed: ") + strerror(rc < 0 ? -rc : rc));
       stats().t_unmap += now_ns() - t0;
-      for (size_t k = i; k < j; ++k) cleared[zorder[k]] = 1;
-      i = j;
+      // the extents these pages belong to, in address order: neighbours share theirs, so the list stays short
+      if (own_direct)
+        for (size_t k = run.first; k < run.first + run.count; ++k) {
+          const phys_handle_t h = run.r->handle[k];
+          if (run.r->mapped[k] == 1 && is_piece(h)) ++touched.at(chunk_of(h));
+        }
     }
   }
+  sg.mark(12);
   size_t max_clear = (size_t)options().clear_run_slots.load();
   if (max_clear >= 2 && xpool->multi_page()) max_clear = std::max<size_t>(max_clear, xpool->max_extent_pages()); // a whole extent in one go
   if (max_clear >= 2 && slots.size() >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
@@ -1518,7 +1540,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     r.mapped[s.index] = 0;
     gone.emplace_back(&r, s.index);
     ++u.n;
-    if (own && own_direct && is_piece(r.handle[s.index])) touched.push_back(chunk_of(r.handle[s.index])); // (a tagged handle of our own pool: a page of a multi-page extent)
+    if (own && own_direct && cleared[si] != 2 && is_piece(r.handle[s.index])) ++touched.at(chunk_of(r.handle[s.index])); // (a tagged handle of our own pool: a page of a multi-page extent; those of the runs above are counted already)
     if (r.rest_direct()) {
       // Its rest state is back already (REPLACE above). In compat mode the invalidation happens inside this call:
       // "unbacked VA reads as zeros" holds from the moment unmap returns (an asynchronous invalidation would let a read
@@ -1539,24 +1561,23 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
     }
   }
   flush_run();
-  if (!touched.empty() && !env_bool("KVCACHED_TEST_SKIP_REMAINDER_REFRESH", false)) { // hook: prove the test has teeth
-    std::sort(touched.begin(), touched.end());
-    for (size_t i = 0; i < touched.size();) {
-      size_t j = i;
-      while (j < touched.size() && touched[j] == touched[i]) ++j;
+  sg.mark(13);
+  if (!touched.items().empty() && !env_bool("KVCACHED_TEST_SKIP_REMAINDER_REFRESH", false)) { // hook: prove the test has teeth
+    for (auto &kv : touched.items()) {
       // pieces still handed out beyond the ones this batch takes back = pages of the extent that stay mapped
-      if (xpool->pieces_out(touched[i]) > j - i)
-        if (void *bo = DrmVm::instance().find(touched[i]))
+      if (xpool->pieces_out(kv.first) > kv.second)
+        if (void *bo = DrmVm::instance().find(kv.first))
           if (!DrmVm::instance().refresh_mappings_of(bo, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of an extent failed");
-      i = j;
     }
     tlb_stale().store(true);
   }
+  sg.mark(14);
   { // every driver call that removed or rewrote a translation has returned: the next invalidation to START covers them all
     const uint64_t epoch = ctx->next_flush_epoch();
     for (auto &g : gone) g.first->stale_epoch[g.second] = epoch;
     u.epoch = epoch;
   }
+  sg.mark(15);
 }
 
 // TLB invalidation, then the handles go back to the pool / the driver. Touches no allocator state (the async
@@ -1579,6 +1600,7 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   //     is left to its next 100 ms tick (GpuContext::housekeeping) - the 0.3-0.4 ms KFD round trip leaves the
   //     caller's free() and, unless an alloc follows within that tick, reaches nobody's critical path
   //     (KVCACHED_ASYNC_SHOOTDOWN, on by default; one page id: free() 0.6 -> 0.2 ms).
+  SegTimer sg;
   const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
   if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer) {
     // (starting it on the context's thread and overlapping the scrub launch and the pool with it was tried: the thread
@@ -1591,6 +1613,7 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   for (auto h : u.imported) {
     if (!vmm_try_release(h)) KVC_LOG(LOG_ERROR, "releasing an imported handle failed");
   }
+  sg.mark(16);
   const int64_t tr0 = now_ns();
   // Zero the pages on their way back: the fill is queued (through the alias mappings of their buffers) BEFORE they are on
   // offer again, and whoever gets them next only waits for that ticket (GpuContext::scrub).
@@ -1599,7 +1622,9 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
     std::vector<uint64_t> addrs(u.own.size());
     if (pool->scrub_addresses(u.own.data(), u.own.size(), addrs.data())) ticket = ctx->scrub(addrs.data(), addrs.size(), u.page_size);
   }
+  sg.mark(17);
   pool->release_batch(u.own.data(), u.own.size(), ticket);
+  sg.mark(18);
   stats().t_release += now_ns() - tr0;
   stats().pages_unmapped += u.n;
 }

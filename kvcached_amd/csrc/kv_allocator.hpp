@@ -61,12 +61,22 @@ struct Stats {
   std::atomic<int64_t> unmaps_queued{0}, unmaps_cancelled{0}; // async unmap: slots queued / re-backed before the reclaimer got to them
   // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
   std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
+  // host time of the map / unmap calls by segment (diagnostics, read-only options 130 + i; names in c_api.cpp)
+  std::atomic<int64_t> seg[20] = {};
   std::mutex mu;
   double fill_ms = 0, compact_ms = 0;
   VmmCounters vmm;
   void reset();
 };
 Stats &stats();
+struct SegTimer { // accumulates the time since the previous mark into stats().seg[i]
+  int64_t t = now_ns();
+  void mark(int i) {
+    const int64_t n = now_ns();
+    stats().seg[i] += n - t;
+    t = n;
+  }
+};
 std::atomic<int64_t> &background_shootdowns(); // TLB invalidations performed off the callers' threads (option 111)
 
 // Per-device state: stream for our kernels, event pool for per-launch timing, handle pools.
@@ -104,6 +114,7 @@ public:
   uint64_t scrub(const uint64_t *alias_addrs, size_t n, size_t page_bytes);
   void wait_scrub(uint64_t ticket);
   void wait_all_scrubs() { wait_scrub(scrub_issued_.load()); }
+  uint64_t scrubs_issued() const { return scrub_issued_.load(); }
   // VA for alias mappings (never handed to anybody): carved from arenas reserved 64 GiB at a time
   uint64_t alias_alloc(size_t bytes);
   void alias_free(uint64_t va, size_t bytes);
@@ -189,6 +200,9 @@ private:
   hipStream_t scrub_stream_ = nullptr;
   std::mutex scrub_mu_; // launch order = ticket order
   std::atomic<uint64_t> scrub_issued_{0}, scrub_done_{0};
+  std::deque<std::pair<uint64_t, hipEvent_t>> scrub_events_; // (ticket, recorded behind its launch), ascending; under scrub_mu_
+  std::vector<hipEvent_t> scrub_free_events_;
+  void retire_scrubs_locked(uint64_t through); // entries <= through are over
   struct Arena {
     char *base;
     size_t size, used;
@@ -249,6 +263,7 @@ struct KvRegion {
   size_t reg_group = 1;
   std::vector<hipMemGenericAllocationHandle_t> shell, shell_group;
   bool in_full_group(size_t slot) const { return reg_group > 1 && slot / reg_group < num_slots() / reg_group; }
+  std::vector<uint64_t> mark;          // one bit per slot, all clear at rest: scratch of RunScan (kv_allocator.cpp), under the allocator's lock
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
                                        // 3 = released by the caller, physical unmap still queued (async unmap)
   size_t num_slots() const { return size / page_size; }

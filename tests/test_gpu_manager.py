@@ -79,6 +79,13 @@ NUM_LAYERS, BLOCK_SIZE, NUM_BLOCKS = 16, 16, 65536
 KV_SHAPE = (2, NUM_BLOCKS, BLOCK_SIZE, 8, 64)
 
 
+@pytest.fixture(autouse=True)
+def _no_reserve_unless_asked(monkeypatch):
+    """Exact handle counts and early recycling: no pre-created reserve (KVCACHED_PHYS_RESERVE_MB, default 2 GiB) unless
+    a test sets one itself."""
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", os.environ.get("KVC_TEST_RESERVE_MB", "0"))
+
+
 @pytest.fixture()
 def manager(monkeypatch):
     import kvcached_amd.kv_cache_manager as kcm

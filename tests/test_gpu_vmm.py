@@ -21,7 +21,13 @@ def vmm():
     """Fresh allocator per test (compat defaults: zero backfill on, zero fill on)."""
     from kvcached_amd import capi, vmm_ops
     state = {"ops": vmm_ops, "capi": capi}
+    # no pre-created reserve unless a test asks for one: these tests count handles and want RECYCLED pages early (with the
+    # default 2 GiB of never-used pages on offer, the oldest idle first, a small test would not see a recycled page at all)
+    had = os.environ.get("KVCACHED_PHYS_RESERVE_MB")
+    os.environ.setdefault("KVCACHED_PHYS_RESERVE_MB", "0")
     yield state
+    if had is None:
+        os.environ.pop("KVCACHED_PHYS_RESERVE_MB", None)
     vmm_ops.shutdown_kvcached()
     capi.set_option(capi.OPT_ZERO_BACKFILL, 1)
     capi.set_option(capi.OPT_ZERO_FILL, 1)
@@ -115,6 +121,7 @@ _CONFIGS = [(b, mode, au, ck, "") for b in ("drm", "hybrid", "hip") for mode in 
 _CONFIGS += [("drm", mode, 0, 64, off) for mode in ("lazy", "compat")
              for off in ("KVCACHED_SCRUB_ON_RELEASE=false", "KVCACHED_KFD_TLB_FLUSH=false", "KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES=true",
                          "KVCACHED_ASYNC_SHOOTDOWN=false")]
+_CONFIGS += [("drm", mode, 0, ck, "KVCACHED_PHYS_RESERVE_MB=48") for mode in ("lazy", "compat") for ck in (1, 64)]   # never-used and recycled pages mixed
 _CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("drm", "lazy", 1, 64, "KVCACHED_PRT=false"),
              ("drm", "lazy", 0, 64, "KVCACHED_PRT=false"), ("drm", "compat", 0, 64, "KVCACHED_PRT=false"),   # zero extent / unmapped VA
              ("drm", "compat", 0, 1, "KVCACHED_PRT=false")]
@@ -546,6 +553,40 @@ def test_pages_are_zeroed_on_their_way_back_not_on_their_way_out(vmm, monkeypatc
         ops.shutdown_kvcached()
         st = capi.get_stats()
         assert st["handles_created"] == st["handles_released"]
+
+
+def test_the_first_creation_brings_the_reserve_along_and_a_cycle_never_waits_for_its_own_scrub(vmm, monkeypatch):
+    """DESIGN.md §4.9. Pages are zeroed on their way back; a free()+alloc() cycle that had to take the pages it has just given
+    back would wait for that fill. The first extents a pool creates therefore bring KVCACHED_PHYS_RESERVE_MB of idle memory
+    along (sized like themselves, created in that same call - a bare C-ABI caller has no watcher thread to do it later), the
+    pool hands out what has been idle longest, and the cycle alternates between two sets of pages."""
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "128")          # 64 pages
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=512 * PAGE, backfill=True, kv=1, unified=True)
+    if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+        pytest.skip("needs the drm backend with pages straight from KFD")
+    t, epp = ts[0], PAGE // 2
+    offs = [i * PAGE for i in range(64)]
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors(offs)
+    st = capi.get_stats()
+    assert st["handles_created"] == 64 + 64                          # its own pages + the reserve
+    assert capi.get_option(120) == 128 and capi.get_option(121) == 64   # held / handed out
+    first = set()
+    for cycle in range(6):
+        for o in offs:
+            assert int(torch.count_nonzero(t[o // 2:o // 2 + epp])) == 0, cycle
+        t[:64 * epp] = 0x1234 + cycle
+        torch.cuda.synchronize()
+        assert ops.unmap_from_kv_tensors(offs)
+        assert int(torch.count_nonzero(t[:64 * epp])) == 0           # compat: zeros from the moment unmap returns
+        assert ops.map_to_kv_tensors(offs)
+    st = capi.get_stats()
+    assert st["handles_created"] == 128                              # nothing created after the first call
+    assert capi.get_option(capi.OPT_PAGES_PRESCRUBBED) >= 4 * 64     # from the third cycle on every page arrives zeroed
+    assert ops.unmap_from_kv_tensors(offs)
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
 
 
 _TLB_CHILD = r"""
