@@ -52,8 +52,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--mode", choices=["lazy", "compat"], default="compat",
-                    help="compat (library default, the reference's semantics): unbacked VA shows zeros (the pages of one zero "
-                         "extent); lazy (KVCACHED_ZERO_BACKFILL=false): unbacked VA stays unmapped, a stray access faults")
+                    help="compat (library default, the reference's semantics): unbacked VA reads as zeros (a PRT mapping), a map "
+                         "batch invalidates the TLBs before its pages are used; lazy (KVCACHED_ZERO_BACKFILL=false): unbacked VA "
+                         "stays unmapped, a stray access faults, and neither call waits for an invalidation")
     ap.add_argument("--pool-mb", type=int, default=None, help="idle physical-handle pool cap (default: library default)")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra per-mode runs at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -590,7 +591,7 @@ def main():
                     "tlb_flush_through_hipMalloc_instead_of_kfd": V(env={"KVCACHED_KFD_TLB_FLUSH": "false"}),
                     "zero_extent_instead_of_prt": V(env={"KVCACHED_PRT": "false"}),
                     "lazy_mode_opt_in": V(mode="lazy"),
-                    "lazy_mode_unmapped_va_instead_of_prt_round1": V(mode="lazy", env={"KVCACHED_PRT": "false"}),
+                    "lazy_mode_with_prt_behind_unbacked_va": V(mode="lazy", env={"KVCACHED_PRT": "true"}),
                     "lazy_mode_map_waits_for_all_invalidations": V(mode="lazy", env={"KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES": "true"}),
                     "lazy_mode_fill_in_the_map_call": V(mode="lazy", env={"KVCACHED_SCRUB_ON_RELEASE": "false"}),
                     "compat_sharded_zero_pages_through_rocr_round1": V(mode="compat", n=8, env={"KVCACHED_ZERO_EXTENT": "false", "KVCACHED_PRT": "false"}),

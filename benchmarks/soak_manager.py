@@ -42,8 +42,8 @@ def main():
         os.environ["KVCACHED_PHYS_POOL_MB"] = str(args.pool_mb)
     if args.extent_pages is not None:
         os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = str(args.extent_pages)
-    if args.touch_unbacked and not args.compat and os.environ.get("KVCACHED_PRT", "true").lower() in ("0", "false"):
-        raise SystemExit("--touch-unbacked needs PRT or --compat: unmapped VA faults")
+    if args.touch_unbacked and not args.compat:
+        os.environ["KVCACHED_PRT"] = "true"        # lazy mode leaves unbacked VA unmapped by default: touching it would fault
     if args.touch_unbacked and (args.prealloc or args.async_unmap):
         # A slot IN TRANSITION is not at rest: inside the one ioctl that replaces PRT by a page (or back) the kernel first
         # clears the range and then writes the new entries, and a GPU access that lands in that window faults (found the

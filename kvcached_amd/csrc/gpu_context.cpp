@@ -345,6 +345,8 @@ void GpuContext::wait_scrub(uint64_t ticket) {
         break;
       }
   }
+  static const bool whole_stream = env_bool("KVCACHED_TEST_SCRUB_WAIT_STREAM", false); // diagnostics: the previous behaviour
+  if (whole_stream) ev = nullptr;
   if (ev) {
     HIP_CHECK(hipEventSynchronize(ev)); // (should the event be recycled meanwhile, this waits for a later scrub: longer, never shorter)
     std::lock_guard<std::mutex> g(scrub_mu_);
@@ -559,13 +561,12 @@ void GpuContext::ensure_flushed() {
   if (tlb_stale().load()) do_shootdown();
 }
 
-void GpuContext::request_async_flush(bool urgent) {
+void GpuContext::request_async_flush() {
   {
     std::lock_guard<std::mutex> g(fl_mu_);
     if (fl_stop_) return;
     if (!flusher_.joinable()) flusher_ = std::thread([this] { flusher_loop(); });
     fl_kick_ = true;
-    fl_urgent_ = fl_urgent_ || urgent;
   }
   fl_cv_.notify_one();
 }
@@ -578,8 +579,6 @@ void GpuContext::flusher_loop() {
     fl_cv_.wait(lk, [&] { return fl_stop_ || fl_kick_; });
     if (fl_stop_) break;
     fl_kick_ = false;
-    const bool urgent = fl_urgent_; // somebody is going to wait for this one at the end of his call: no yielding
-    fl_urgent_ = false;
     lk.unlock();
     // The invalidation and the page-table ioctls of a map or unmap call serialise in the kernel (a REPLACE issued while
     // the KFD pair is in flight waits for most of its 0.4 ms). Nobody is waiting for THIS invalidation - whoever needs
@@ -587,7 +586,7 @@ void GpuContext::flusher_loop() {
     // been active for 150 us, or after 2 ms at the latest (an engine that frees and allocates in one scheduler step
     // gets its alloc through first; a tight loop is invalidated every few iterations instead of behind every one).
     const int64_t t0 = now_ns();
-    while (!urgent && foreground_busy() && now_ns() - t0 < 2000000) std::this_thread::sleep_for(std::chrono::microseconds(40));
+    while (foreground_busy() && now_ns() - t0 < 2000000) std::this_thread::sleep_for(std::chrono::microseconds(40));
     try {
       ensure_flushed();
     } catch (const std::exception &e) {

@@ -286,7 +286,7 @@ inline void vmm_map_pieces(void *va, size_t piece_bytes, size_t count, phys_hand
 }
 // The same over slots that currently show something else (compat mode: aliases of the zero extent): whatever is mapped in
 // the range is dropped or split and the pieces take its place, in ONE ioctl (AMDGPU_VA_OP_REPLACE).
-// `live`: the translations being replaced are valid ones (zero aliases) - PRT entries are not, and owe no invalidation.
+// `live`: the translations being replaced may sit in a TLB (zero aliases; PRT entries too once they have been looked at).
 inline void vmm_replace_pieces(void *va, size_t piece_bytes, size_t count, phys_handle_t h_first, bool live) {
   struct MaybeStale {
     bool on;

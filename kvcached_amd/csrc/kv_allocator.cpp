@@ -636,9 +636,14 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // reservation; on ROCm hipMemUnmap of an alias costs O(aliases of that handle) (~6 ns each: 37 us
 // per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
 // the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
-// The rest state of unbacked slots on the drm backend: PRT (DrmVm::map_prt). One ioctl for the whole region.
-bool KvAllocator::prt_all(KvRegion &r) {
-  if (!dev_.is_gpu || vmm_backend() != kVmmDrm || !DrmVm::instance().can_clear() || !env_bool("KVCACHED_PRT", true)) return false;
+// The rest state of unbacked slots on the drm backend where reads of them must not fault: PRT (DrmVm::map_prt), one ioctl
+// for the whole region. Default in compat mode. NOT in lazy mode: a PRT translation IS cached by the TLBs once something
+// has looked at the address (tools/prt_tlb_probe.cpp: every read stale and 0.8 % of the writes lost after backing such
+// slots without an invalidation), so backing a PRT slot owes an invalidation before the page is used - and lazy mode's
+// contract (nothing touches unbacked VA) is what makes its map path free of one: plain unmapped VA, where a violation
+// faults instead of poisoning the next mapping. KVCACHED_PRT=true|false overrides either default.
+bool KvAllocator::prt_all(KvRegion &r, bool by_default) {
+  if (!dev_.is_gpu || vmm_backend() != kVmmDrm || !DrmVm::instance().can_clear() || !env_bool("KVCACHED_PRT", by_default)) return false;
   hipDeviceProp_t prop{};
   if (hipGetDeviceProperties(&prop, ctx_->dev()) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     (void)hipGetLastError();
@@ -671,7 +676,7 @@ int KvAllocator::rest_map(KvRegion &r, size_t first, size_t n) {
 }
 
 void KvAllocator::backfill_all(KvRegion &r) {
-  if (prt_all(r)) { // "reads as zeros" from the page tables themselves: no zero page, no invalidation on the map path
+  if (prt_all(r, true)) { // "reads as zeros" from the page tables themselves: no zero page to keep and to alias
     r.backfilled = true;
     return;
   }
@@ -907,7 +912,7 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
     if (backfill)
       backfill_all(*r);
     else
-      (void)prt_all(*r); // lazy mode: unbacked VA does not fault either where PRT is to be had
+      (void)prt_all(*r, false); // lazy mode: unmapped VA unless KVCACHED_PRT=true asks for PRT
     out.push_back({r->base, r->size});
     layers_.push_back(std::move(r));
   } else {
@@ -922,7 +927,7 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
         if (backfill)
           backfill_all(*r);
         else
-          (void)prt_all(*r);
+          (void)prt_all(*r, false);
         layers_.push_back(std::move(r));
       }
     }
@@ -1231,12 +1236,12 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       if (hip_reg && !r.registered[s.index]) register_slot(r, s.index); // once per slot
       if (r.rest_direct() && !chunked) { // (chunked: replaced run by run below)
         if (DrmVm::instance().clear(va, ps) != 0) throw GpuError("dropping the rest mapping of a slot failed");
-        if (r.zx) { // a zero alias was a live translation (a PRT entry is not)
-          tlb_stale().store(true);
-          zx_dirty = DrmVm::instance().find(r.zx_handle);
-          dirty_tlb = true;
-          need_epoch = ctx->next_flush_epoch();
-        }
+        // a zero alias was a live translation, and so - for the TLBs - is a PRT entry that something has looked at
+        // (tools/prt_tlb_probe.cpp): an invalidation is owed before the page is used
+        tlb_stale().store(true);
+        if (r.zx) zx_dirty = DrmVm::instance().find(r.zx_handle);
+        dirty_tlb = true;
+        need_epoch = ctx->next_flush_epoch();
       } else if (r.backfilled && !r.rest_direct()) {
         vmm_unmap(va, ps);
         dirty_tlb = true; // the alias's translation is live
@@ -1323,12 +1328,15 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           char *va = r.base + at * ps;
           try {
             if (r.rest_direct()) { // the slots carry their rest mapping: pages take its place in the same ioctl
-              vmm_replace_pieces(va, ps, n, got[0].h, /*live=*/r.zx);
-              if (r.zx) { // zero aliases were live translations: rewrite the split remainders, invalidate before use
-                zx_dirty = DrmVm::instance().find(r.zx_handle);
-                dirty_tlb = true;
-                need_epoch = ctx->next_flush_epoch();
-              } // (PRT entries are invalid ones: never cached, nothing owed - tools/prt_probe.cpp stage 4)
+              vmm_replace_pieces(va, ps, n, got[0].h, /*live=*/true);
+              // What was there may sit in a TLB: a zero alias is a live translation (and the split remainders of its
+              // mapping are rewritten first), and a PRT entry is cached like one as soon as anything has read or written
+              // the address (tools/prt_tlb_probe.cpp: after a chip-wide read of PRT slots, backing them without an
+              // invalidation left every read stale and lost 0.8 % of the writes). Invalidate before use.
+              if (r.zx) zx_dirty = DrmVm::instance().find(r.zx_handle);
+              tlb_stale().store(true);
+              dirty_tlb = true;
+              need_epoch = ctx->next_flush_epoch();
             } else {
               vmm_map_pieces(va, ps, n, got[0].h);
             }

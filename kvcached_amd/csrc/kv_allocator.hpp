@@ -155,8 +155,7 @@ public:
   // Have this context's own thread do ensure_flushed() right away (started on first use): the unmap path's 0.3-0.5 ms
   // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
   // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
-  // `urgent`: the caller will wait for it (ensure_flushed_through) at the end of what he is doing - start at once
-  void request_async_flush(bool urgent = false);
+  void request_async_flush();
   // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
   struct Foreground {
     GpuContext *c;
@@ -191,7 +190,7 @@ private:
   std::thread flusher_;
   std::mutex fl_mu_;
   std::condition_variable fl_cv_;
-  bool fl_stop_ = false, fl_kick_ = false, fl_urgent_ = false;
+  bool fl_stop_ = false, fl_kick_ = false;
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
@@ -314,7 +313,7 @@ private:
   std::unique_ptr<KvRegion> make_region(const std::string &name, size_t size, size_t page_size);
   void destroy_region(KvRegion &r);
   void backfill_all(KvRegion &r);
-  bool prt_all(KvRegion &r);                       // PRT behind every slot of the region (false: not available)
+  bool prt_all(KvRegion &r, bool by_default);      // PRT behind every slot of the region (false: not available / not wanted)
   int rest_replace(KvRegion &r, size_t first, size_t n); // slots [first, first+n) back to their rest state in one ioctl, whatever is mapped there
   int rest_map(KvRegion &r, size_t first, size_t n);     // the same over slots that hold nothing
   void register_slot(KvRegion &r, size_t slot);   // hybrid backend: make HIP aware of the slot's VA (once per slot)

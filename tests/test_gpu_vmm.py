@@ -122,8 +122,9 @@ _CONFIGS += [("drm", mode, 0, 64, off) for mode in ("lazy", "compat")
              for off in ("KVCACHED_SCRUB_ON_RELEASE=false", "KVCACHED_KFD_TLB_FLUSH=false", "KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES=true",
                          "KVCACHED_ASYNC_SHOOTDOWN=false")]
 _CONFIGS += [("drm", mode, 0, ck, "KVCACHED_PHYS_RESERVE_MB=48") for mode in ("lazy", "compat") for ck in (1, 64)]   # never-used and recycled pages mixed
-_CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("drm", "lazy", 1, 64, "KVCACHED_PRT=false"),
-             ("drm", "lazy", 0, 64, "KVCACHED_PRT=false"), ("drm", "compat", 0, 64, "KVCACHED_PRT=false"),   # zero extent / unmapped VA
+_CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("drm", "lazy", 1, 64, "KVCACHED_PRT=true"),
+             ("drm", "lazy", 0, 64, "KVCACHED_PRT=true"), ("drm", "lazy", 0, 1, "KVCACHED_PRT=true"),      # lazy with PRT (opt-in)
+             ("drm", "compat", 0, 64, "KVCACHED_PRT=false"),                                              # zero extent
              ("drm", "compat", 0, 1, "KVCACHED_PRT=false")]
 
 
@@ -142,7 +143,8 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
     if switch:
         monkeypatch.setenv(*switch.split("="))
     ops, capi, ts = _setup(vmm, layers=2, per_layer=64 * PAGE, backfill=(mode == "compat"), kv=1, unified=False)
-    assert capi.get_option(capi.OPT_PRT) == int(backend == "drm" and switch != "KVCACHED_PRT=false")
+    # PRT behind unbacked VA: the compat default on the drm backend; lazy mode leaves unbacked VA unmapped unless asked
+    assert capi.get_option(capi.OPT_PRT) == int(backend == "drm" and (switch == "KVCACHED_PRT=true" or (mode == "compat" and switch != "KVCACHED_PRT=false")))
     want_backend = {"drm": 3, "hybrid": 2, "hip": 0}[backend]
     assert capi.get_option(108) == want_backend
     assert capi.get_option(capi.OPT_ASYNC_UNMAP) == async_unmap
@@ -270,12 +272,13 @@ def test_deferred_unmap_shootdown_keeps_pages_private(vmm):
 
 
 def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, monkeypatch):
-    """Unmaps invalidate the TLBs (the VMM calls do not); maps need to only where something valid may still be cached:
-    a zero alias being replaced (compat mode WITHOUT PRT: a PRT entry is an invalid one) or an invalidation somebody
-    deferred. Mapping an unbacked slot whose
-    last unmap was invalidated needs nothing - an invalid translation is never cached on GFX9+ (KFD itself flushes
-    after unmap only on this GPU family; tools/drm_vmm_probe.cpp mode 3). Data check: pages recycled through the
-    pool land on other slots between live neighbours and read zeros, neighbours keep their contents."""
+    """Unmaps invalidate the TLBs (the VMM calls do not); maps need to only where something may still be cached for the
+    address: a zero alias or a PRT entry being replaced (compat mode: a PRT entry is cached like a valid one once anything has
+    looked at the address, tools/prt_tlb_probe.cpp) or an invalidation somebody deferred. Mapping an UNMAPPED slot (lazy
+    mode) whose last unmap was invalidated needs nothing - an invalid translation is never cached on GFX9+ (KFD itself
+    flushes after unmap only on this GPU family; tools/drm_vmm_probe.cpp mode 3), and nothing can have looked at it
+    without faulting. Data check: pages recycled through the pool land on other slots between live neighbours and read
+    zeros, neighbours keep their contents."""
     epp = PAGE // 2
     for mode, per_map in (("lazy", 0), ("compat", 1), ("compat-zero-extent", 1), ("always", 1)):
         if mode == "always":
@@ -286,8 +289,7 @@ def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, mon
         else:
             monkeypatch.delenv("KVCACHED_PRT", raising=False)
         ops, capi, ts = _setup(vmm, layers=1, per_layer=64 * MiB, backfill=(mode == "compat"), kv=1, unified=True)
-        if mode == "compat" and capi.get_option(capi.OPT_PRT):
-            per_map = 0                                                    # nothing valid is replaced: no invalidation on the map path
+        assert capi.get_option(capi.OPT_PRT) == int(mode == "compat" and os.environ.get("KVCACHED_PRT") != "false" and capi.get_option(108) == 3)
         t = ts[0]
         capi.reset_stats()
         even = [s * PAGE for s in range(0, 32, 2)]
@@ -312,6 +314,31 @@ def test_map_batches_invalidate_only_when_a_stale_translation_can_exist(vmm, mon
             assert capi.get_stats()["tlb_shootdowns"] == n1 + 1, (mode, r)   # every unmap batch invalidates
         assert ops.unmap_from_kv_tensors(even)
         ops.shutdown_kvcached()
+
+
+def test_slots_that_were_looked_at_while_unbacked_are_backed_correctly(vmm):
+    """A PRT translation is cached by the TLBs once anything has looked at the address (tools/prt_tlb_probe.cpp,
+    profiles/r02_prt_tlb_probe.log: after a chip-wide read of 512 PRT slots, backing them with no invalidation left every
+    read stale and lost 0.8 % of the writes). An engine does look at unbacked KV addresses - padded block tables are why the
+    reference keeps a zero page there (csrc/ftensor.cpp:160-176) - so in compat mode a map batch invalidates before its
+    pages are used. Here: chip-wide reads of every unbacked slot, then back them all, write every word, invalidate (an
+    unmap elsewhere), read every word back."""
+    ops, capi, ts = _setup(vmm, layers=1, per_layer=260 * PAGE, backfill=True, kv=1, unified=True)
+    t = ts[0]                                             # int16 elements
+    epp = PAGE // 2
+    n = 256
+    for rnd in range(3):
+        assert int(t[:n * epp:64].to(torch.int64).sum()) == 0          # every unbacked slot, one word per 128 B, read chip-wide
+        n0 = capi.get_stats()["tlb_shootdowns"]
+        assert ops.map_to_kv_tensors([i * PAGE for i in range(n)])
+        if capi.get_option(capi.OPT_PRT):
+            assert capi.get_stats()["tlb_shootdowns"] == n0 + 1        # before anything uses the new pages
+        t[:n * epp] = 0x1357 + rnd                                      # every word
+        torch.cuda.synchronize()
+        assert ops.map_to_kv_tensors([(n + 1) * PAGE]) and ops.unmap_from_kv_tensors([(n + 1) * PAGE])   # an invalidation
+        assert int((t[:n * epp] != 0x1357 + rnd).sum()) == 0, rnd       # no write was dropped, no read is stale
+        assert ops.unmap_from_kv_tensors([i * PAGE for i in range(n)])
+        assert int(t[:n * epp:64].to(torch.int64).sum()) == 0          # zeros again from the moment unmap returns
 
 
 def test_unmap_batches_with_runs_of_neighbours(vmm):
