@@ -71,22 +71,23 @@ int kvc_map_to_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id);
 
 /* Runtime knobs (also read once from the environment at kvc_init):
- *   KVC_OPT_ZERO_BACKFILL  1 (default, as the reference does: csrc/ftensor.cpp:160-176) = unbacked VA reads as zeros from
- *                              the moment an unmap returns. 0 ("lazy", KVCACHED_ZERO_BACKFILL=false) = the TLB
- *                              invalidation an unmap owes runs behind the call on a thread of the library.
- *                              With the drm backend on gfx950 unbacked VA is a PRT mapping in BOTH modes (reads 0,
- *                              writes dropped, no fault, no zero page, no invalidation on the map path: DESIGN.md
- *                              §4.2; kvc_get_option(128)); where PRT is not to be had (KVCACHED_PRT=false, other
- *                              GPUs, the fallback backends) mode 1 aliases zero pages (one zero extent on drm,
- *                              sharded pages through ROCr otherwise) and mode 0 leaves unbacked VA unmapped - a
- *                              stray access then FAULTS.
+ *   KVC_OPT_ZERO_BACKFILL  1 (default, "compat", as the reference does: csrc/ftensor.cpp:160-176) = unbacked VA reads as
+ *                              zeros from the moment an unmap returns: with the drm backend on gfx950 it is a PRT
+ *                              mapping (reads 0, writes dropped, no fault, no zero page: DESIGN.md §4.2;
+ *                              kvc_get_option(128)), elsewhere or with KVCACHED_PRT=false it aliases zero pages (one
+ *                              zero extent on drm, sharded pages through ROCr otherwise); map and unmap calls both
+ *                              invalidate the GPU TLBs before they return (a PRT entry or a zero alias that something
+ *                              has looked at is cached). 0 ("lazy", KVCACHED_ZERO_BACKFILL=false) = unbacked VA is
+ *                              plain unmapped - a stray access FAULTS -, a map call needs no invalidation and the one
+ *                              an unmap owes runs behind the call on a thread of the library (KVCACHED_PRT=true puts
+ *                              PRT behind a lazy region too: harmless stray accesses, invalidating map calls).
  *   KVC_OPT_ZERO_FILL      1 = zero freshly backed pages on the GPU (default), 0 = skip.
  *   KVC_OPT_POOL_BYTES     max bytes of idle physical handles kept for reuse.
  *   KVC_OPT_PROFILE        1 = time every kernel launch with HIP events (bench.py).
  *   KVC_OPT_TLB_SHOOTDOWN  1 (default) = force the driver to invalidate the GPU TLBs after every batch of unmaps, and
  *                              after a batch of maps when a translation of the affected VA or pages can still be
- *                              cached (zero alias replaced, deferred invalidation outstanding; a translation that
- *                              was invalid is never cached on GFX9+, so mapping an unbacked slot needs none;
+ *                              cached (zero alias or PRT entry replaced, deferred invalidation outstanding; a
+ *                              translation of an UNMAPPED address is never cached on GFX9+, so backing one needs none;
  *                              KVCACHED_MAP_SHOOTDOWN=always invalidates after every map batch regardless). On
  *                              ROCm 7.2 / MI355X the VMM calls alone leave stale translations behind
  *                              (DESIGN.md §4.3); 0 only for measurements. The invalidation an unmap batch owes is

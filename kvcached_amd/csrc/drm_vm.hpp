@@ -423,8 +423,9 @@ public:
   // A range with no buffer behind it and AMDGPU_VM_PAGE_PRT ("partially resident"): the PTEs are invalid with the PRT bit
   // set - reads return 0, writes are dropped, nothing faults (what Vulkan's sparse resources rest on; checked for
   // compute kernels, blit and copy-engine hipMemcpy and hipMemset on gfx950 by tools/prt_probe.cpp). The rest state of
-  // unbacked KV slots: "reads as zeros" without a zero page, and - an invalid translation is never cached - backing such
-  // a slot needs no TLB invalidation. `replace`: drop or split whatever is mapped in the range first.
+  // unbacked KV slots of a compat region: "reads as zeros" without a zero page. NB the TLBs cache such an entry once
+  // something has looked at the address (tools/prt_tlb_probe.cpp): backing the slot owes an invalidation like replacing
+  // a valid mapping does. `replace`: drop or split whatever is mapped in the range first.
   int map_prt(void *va, size_t size, bool replace = false) {
     if (!can_clear()) return -ENOSYS;
     return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), kVmPagePrt, replace ? kVaOpReplace : kVaOpMap);

@@ -1132,11 +1132,12 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   // mildly with the number of new mappings: 0.31 ms @256, 0.40 ms @1024), then the fill kernel
   // for exactly those slots runs on the GPU while the host issues the driver calls of the next chunk.
   // A TLB invalidation is owed before the new pages are touched only where a translation of these VAs (or of these
-  // pages) may still sit in a TLB: an unmap whose invalidation was deferred, a slot whose zero alias is being
-  // replaced, a page taken from a slot that was released but not yet unmapped. A translation that was INVALID is
-  // never cached on GFX9+ - KFD itself flushes after unmap only on this GPU family, and re-backing slots between busy
-  // neighbours with no invalidation after the map reads back right (tools/drm_vmm_probe.cpp mode 3) - so a plain
-  // map of an unbacked slot whose last unmap was invalidated needs nothing (KVCACHED_MAP_SHOOTDOWN=always restores it).
+  // pages) may still sit in a TLB: an unmap whose invalidation was deferred, a slot whose zero alias or PRT entry is
+  // being replaced, a page taken from a slot that was released but not yet unmapped. The translation of an UNMAPPED
+  // address is never cached on GFX9+ - KFD itself flushes after unmap only on this GPU family, and re-backing slots
+  // between busy neighbours with no invalidation after the map reads back right (tools/drm_vmm_probe.cpp mode 3) - so
+  // a plain map of an unmapped slot whose last unmap was invalidated needs nothing (KVCACHED_MAP_SHOOTDOWN=always
+  // restores it). A PRT entry is another matter: cached once looked at (tools/prt_tlb_probe.cpp).
   const bool always_flush = options().map_shootdown_always.load() != 0;
   bool dirty_tlb = ctx->tlb_owed(); // an invalidation is owed before anything of this batch is touched
   // ... but only the invalidations that cover THESE slots' last unmaps have to be waited for: a stale translation of some

@@ -245,9 +245,10 @@ struct KvRegion {
   bool zx = false;
   phys_handle_t zx_handle = 0;
   size_t zx_pages = 0;
-  // drm backend, the default rest state of unbacked slots in BOTH modes: a PRT mapping with no buffer (DrmVm::map_prt) -
-  // reads return 0, writes are dropped, nothing faults, and backing a slot is invalid -> valid: no TLB invalidation on
-  // the map path. `backfilled` then only says whether an unmap invalidates inside the call (compat) or behind it (lazy).
+  // drm backend, the rest state of unbacked slots of a compat region (a lazy one only with KVCACHED_PRT=true): a PRT
+  // mapping with no buffer (DrmVm::map_prt) - reads return 0, writes are dropped, nothing faults. The TLBs cache such
+  // an entry once it has been looked at, so a map batch that replaces one invalidates before its pages are used (§4.2).
+  // `backfilled` says whether an unmap invalidates inside the call (compat) or behind it (lazy).
   bool prt = false;
   bool rest_direct() const { return zx || prt; }                       // unbacked slots carry a DRM mapping of ours
   size_t rest_group() const { return zx ? zx_pages : (size_t)-1; }     // a REPLACE back to the rest state must not cross this
