@@ -158,7 +158,10 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
       StaleAfter mark;   // a live translation goes away: the invalidation before_release performs covers it
       if (DrmVm::instance().clear(reinterpret_cast<void *>(tag), pages * page_bytes) != 0)
         KVC_LOG(LOG_ERROR, "dropping the alias mapping of a buffer failed");
-      alias_free(tag, pages * page_bytes);
+      // the address is on offer again only AFTER the invalidation below: a new buffer mapped there earlier could have its
+      // scrub go through a cached translation of the old one
+      std::lock_guard<std::mutex> g(arena_mu_);
+      alias_limbo_.emplace_back(tag, pages * page_bytes);
     };
     d.release = [](phys_handle_t h) {
       const bool ok = vmm_try_release(h);
@@ -166,7 +169,15 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
       (void)hipGetLastError();
       return ok;
     };
-    d.before_release = [this]() { flush_deferred_shootdown(); }; // memory leaves the process: no translation of it may survive
+    d.before_release = [this]() { // memory leaves the process: no translation of it may survive
+      std::vector<std::pair<uint64_t, size_t>> mine;
+      {
+        std::lock_guard<std::mutex> g(arena_mu_);
+        mine.swap(alias_limbo_); // (what another thread adds from here on is covered by ITS invalidation, not by this one)
+      }
+      flush_deferred_shootdown();
+      for (auto &a : mine) alias_free(a.first, a.second);
+    };
     d.under_pressure = device_under_pressure;
     m[page_bytes] = std::make_unique<ExtentPool>(page_bytes, k, std::move(d), &stats().vmm);
     it = m.find(page_bytes);

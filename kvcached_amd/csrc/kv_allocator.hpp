@@ -209,6 +209,7 @@ private:
   std::mutex arena_mu_;
   std::vector<Arena> arenas_;
   std::map<size_t, std::vector<uint64_t>> alias_free_; // by size: extents come in a handful of sizes
+  std::vector<std::pair<uint64_t, size_t>> alias_limbo_; // alias addresses whose mapping is gone but not yet invalidated (arena_mu_)
   struct ZeroExtent {
     phys_handle_t h;
     size_t pages;
