@@ -71,7 +71,8 @@ def parse_args():
 HOST_SEGMENTS = {0: "map: offsets to slots", 1: "map: classify slots", 2: "map: sort into runs", 3: "map: pool", 4: "map: page-table ioctls",
                  5: "map: per-run bookkeeping", 6: "map: invalidation owed", 7: "map: wait for own fill", 8: "map: wait for the scrub of these pages", 9: "map: scrubs behind the newest (count, x1000)", 10: "unmap: offsets to slots", 11: "unmap: sort into runs",
                  12: "unmap: page-table ioctls", 13: "unmap: per-slot bookkeeping", 14: "unmap: remainders of split mappings",
-                 15: "unmap: epochs", 16: "unmap: TLB invalidation", 17: "unmap: scrub launch", 18: "unmap: pool"}
+                 15: "unmap: epochs", 16: "unmap: TLB invalidation", 17: "unmap: scrub launch", 18: "unmap: pool",
+                 19: "both: re-MAP half of the KFD pairs (the UNMAP half is the flush itself)"}
 
 
 def batch_offsets(batch_index: int, seed: int = 0, slot: int = PAGE):

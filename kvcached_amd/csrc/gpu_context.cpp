@@ -647,7 +647,9 @@ void GpuContext::do_shootdown() {
   } else if (kfd_flush_.ready()) {
     // The ioctl pair that ends in KFD's heavyweight flush, on our own buffer: nothing between us and the kernel can
     // answer it from a cache.
-    if (!kfd_flush_.flush()) throw GpuError(std::string("KFD TLB flush failed: ") + strerror(errno));
+    int64_t map_ns = 0;
+    if (!kfd_flush_.flush(&map_ns)) throw GpuError(std::string("KFD TLB flush failed: ") + strerror(errno));
+    stats().seg[19] += map_ns; // (diagnostics, option 149: the re-MAP half of the pair; the UNMAP half is the flush itself)
   } else {
     // Fallback where /dev/kfd cannot be driven directly: an allocation that reaches KFD. 2 MiB is the smallest size
     // ROCr does not serve from its sub-allocator (measured: 4 KiB has no effect, 2 MiB ~0.22 ms). A real trip to the

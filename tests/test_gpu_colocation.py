@@ -135,9 +135,11 @@ def test_two_engines_share_one_gpu():
         got = _ask(b, "alloc", 4 * BLOCKS_PER_GIB)
         assert got == 4 * BLOCKS_PER_GIB, (got, b0, b2)
 
-        # now B holds 4 GiB; A asks for 6 again: does not fit -> None, allocator state untouched; 3 GiB does fit
+        # now B holds 4 GiB (3-4 of them from the device, depending on whether its housekeeping has refilled the reserve it
+        # dipped into): A sees 4-5 GiB of the device + its own reserve + a few straggler extents, at most 6.2 GiB. 7 does not
+        # fit -> None, allocator state untouched; 3 GiB does fit
         a2 = _ask(a, "avail")
-        got = _ask(a, "alloc", 6 * BLOCKS_PER_GIB)
+        got = _ask(a, "alloc", 7 * BLOCKS_PER_GIB)
         assert got is None, (got, a0, a2)
         got = _ask(a, "alloc", 3 * BLOCKS_PER_GIB)
         assert got == 3 * BLOCKS_PER_GIB, (got, a0, a2)
