@@ -451,6 +451,25 @@ public:
     if (!can_clear()) return -ENOSYS;
     return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), kVmPagePrt, replace ? kVaOpReplace : kVaOpMap);
   }
+  // After slots were REPLACEd (or CLEARed) out of a larger PRT mapping: what is left of it keeps page-table entries that
+  // carry the FRAGMENT size of the original mapping, and a TLB that caches one of them - PRT entries are cached once
+  // looked at - goes on answering for the whole fragment, backed slots included: they read as zeros and swallow writes
+  // (tools/prt_tlb_probe.cpp, "neighbours": 255 of 256 backed slots shadowed, for good, invalidations or not). The kernel
+  // has the remainders queued to be written again at the next update of their owner, and all PRT mappings of one DRM file
+  // share one owner: ONE PRT operation anywhere does it (same probe: 0 wrong reads afterwards). The caller invalidates
+  // the TLBs afterwards. Same hazard and same cure as refresh_mappings_of() for buffers.
+  bool refresh_prt_remainders() {
+    std::lock_guard<std::mutex> g(scratch_mu_);
+    constexpr size_t kBytes = 2u << 20;
+    if (!prt_scratch_va_) {
+      if (hipMemAddressReserve(&prt_scratch_va_, kBytes, kBytes, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        prt_scratch_va_ = nullptr;
+        return false;
+      }
+    }
+    return map_prt(prt_scratch_va_, kBytes, /*replace=*/true) == 0; // (replace: whatever an earlier call left there goes first)
+  }
   bool can_clear() const { return api_.bo_va_op_raw != nullptr && dev_ != nullptr; }
   int clear(void *va, size_t size) { return api_.bo_va_op_raw(dev_, nullptr, 0, size, reinterpret_cast<uint64_t>(va), 0, kVaOpClear); }
 
@@ -574,6 +593,7 @@ private:
   std::mutex scratch_mu_;
   void *scratch_va_ = nullptr; // one page of reserved VA for refresh_mappings_of()
   size_t scratch_bytes_ = 0;
+  void *prt_scratch_va_ = nullptr; // 2 MiB of reserved VA that refresh_prt_remainders() keeps PRT-mapped
 };
 
 } // namespace kvc

@@ -652,11 +652,21 @@ bool KvAllocator::prt_all(KvRegion &r, bool by_default) {
   // HIP must have been introduced to every slot BEFORE the range is occupied (its placeholder mapping cannot overlap ours)
   for (size_t i = 0; i < r.num_slots(); ++i)
     if (vmm_hip_registered()) register_slot(r, i);
-  const int rc = DrmVm::instance().map_prt(r.base, r.size);
-  if (rc != 0) {
-    KVC_LOG(LOG_WARNING, "PRT mapping refused (%s): unbacked slots fall back to %s", strerror(rc < 0 ? -rc : rc),
-            options().zero_backfill.load() ? "zero aliases" : "unmapped VA");
-    return false;
+  // One mapping per group of 64 slots (2 304 ioctls for the 147 k slots of a 288 GiB reservation), not one for the region:
+  // a page-table entry carries a fragment size that may be as large as its MAPPING, and when a mapping is split what is
+  // left of it has to be written again (DrmVm::refresh_prt_remainders) - that stays a matter of <= 64 entries.
+  const size_t group = KvRegion::kPrtGroupSlots * r.page_size;
+  for (size_t off = 0; off < r.size; off += group) {
+    const int rc = DrmVm::instance().map_prt(r.base + off, std::min(group, r.size - off));
+    if (rc != 0) {
+      KVC_LOG(LOG_WARNING, "PRT mapping refused (%s): unbacked slots fall back to %s", strerror(rc < 0 ? -rc : rc),
+              options().zero_backfill.load() ? "zero aliases" : "unmapped VA");
+      if (off) {
+        StaleAfter mark;
+        (void)DrmVm::instance().clear(r.base, off);
+      }
+      return false;
+    }
   }
   r.prt = true;
   return true;
@@ -1147,7 +1157,15 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   for (auto &s : slots) need_epoch = std::max(need_epoch, s.region->stale_epoch[s.index]);
   const bool blanket = options().map_waits_for_all_flushes.load() != 0;
   void *zx_dirty = nullptr; // compat mode, zero extent: its group mappings were split by this batch's REPLACEs (§4.8's hazard)
+  bool prt_dirty = false;   // PRT mappings were split by this batch: what is left of them carries fragments that span the new pages
   auto flush_for_batch = [&]() {
+    if (prt_dirty) { // rewritten before the invalidation that covers them (DrmVm::refresh_prt_remainders)
+      if (!env_bool("KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH", false) && !DrmVm::instance().refresh_prt_remainders()) // (hook: prove the test has teeth)
+        throw GpuError("rewriting the remainders of split PRT mappings failed");
+      tlb_stale().store(true);
+      need_epoch = ctx->next_flush_epoch();
+      prt_dirty = false;
+    }
     if (zx_dirty) { // the remainders of the zero extent's mappings are rewritten before the invalidation that covers them
       if (!DrmVm::instance().refresh_mappings_of(zx_dirty, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of the zero extent failed");
       tlb_stale().store(true);
@@ -1241,6 +1259,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
         // (tools/prt_tlb_probe.cpp): an invalidation is owed before the page is used
         tlb_stale().store(true);
         if (r.zx) zx_dirty = DrmVm::instance().find(r.zx_handle);
+        if (r.prt) prt_dirty = true;
         dirty_tlb = true;
         need_epoch = ctx->next_flush_epoch();
       } else if (r.backfilled && !r.rest_direct()) {
@@ -1335,6 +1354,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
               // the address (tools/prt_tlb_probe.cpp: after a chip-wide read of PRT slots, backing them without an
               // invalidation left every read stale and lost 0.8 % of the writes). Invalidate before use.
               if (r.zx) zx_dirty = DrmVm::instance().find(r.zx_handle);
+              if (r.prt) prt_dirty = true;
               tlb_stale().store(true);
               dirty_tlb = true;
               need_epoch = ctx->next_flush_epoch();

@@ -252,7 +252,10 @@ struct KvRegion {
   // `backfilled` says whether an unmap invalidates inside the call (compat) or behind it (lazy).
   bool prt = false;
   bool rest_direct() const { return zx || prt; }                       // unbacked slots carry a DRM mapping of ours
-  size_t rest_group() const { return zx ? zx_pages : (size_t)-1; }     // a REPLACE back to the rest state must not cross this
+  // a REPLACE back to the rest state must not cross a multiple of this: the zero extent's pages repeat with that period,
+  // and PRT mappings are kept to groups so that what a split leaves to be rewritten (DrmVm::refresh_prt_remainders) is small
+  static constexpr size_t kPrtGroupSlots = 64;
+  size_t rest_group() const { return zx ? zx_pages : (prt ? kPrtGroupSlots : (size_t)-1); }
   std::vector<phys_handle_t> handle;   // per slot, valid when mapped[slot]
   std::vector<uint64_t> seq;           // per slot: creation order of that handle (release oldest first)
   std::vector<uint64_t> stale_epoch;   // per slot: the TLB invalidation (GpuContext::next_flush_epoch) that covers its last unmap

@@ -341,6 +341,57 @@ def test_slots_that_were_looked_at_while_unbacked_are_backed_correctly(vmm):
         assert int(t[:n * epp:64].to(torch.int64).sum()) == 0          # zeros again from the moment unmap returns
 
 
+_NEIGHBOUR_CHILD = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from kvcached_amd import capi, vmm_ops
+PAGE = 2 << 20
+vmm_ops.init_kvcached("cuda:0", PAGE, False)
+t = vmm_ops.create_kv_tensors(512 * PAGE, 2, "cuda:0", 1, 1, 0, True)[0]      # int16 elements, 512 slots = 8 groups of 64
+epp = PAGE // 2
+bad = 0
+for rnd, step in enumerate((2, 3, 5)):
+    mine = [i for i in range(512) if i %% step == 0]
+    assert vmm_ops.map_to_kv_tensors([i * PAGE for i in mine])
+    for i in mine:
+        t[i * epp:(i + 1) * epp] = 0x100 + rnd
+    torch.cuda.synchronize()
+    for rep in range(3):
+        # the unbacked neighbours are looked at chip-wide (all of them: one word per 128 bytes of the whole region) ...
+        zeros = int(t[::64].to(torch.int64).sum()) - len(mine) * (epp // 64) * (0x100 + rnd)
+        assert zeros == 0 or os.environ.get("KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH"), zeros
+        # ... and the backed slots still show their own pages, not the neighbours' zeros
+        for i in mine:
+            bad += int((t[i * epp:(i + 1) * epp:512] != 0x100 + rnd).sum())
+    assert vmm_ops.unmap_from_kv_tensors([i * PAGE for i in mine])
+print("WRONG WORDS", bad)
+vmm_ops.shutdown_kvcached()
+"""
+
+
+def test_backed_slots_are_not_shadowed_by_their_unbacked_neighbours():
+    """A PRT mapping that a REPLACE has split keeps page-table entries with the fragment size of the ORIGINAL mapping; a TLB
+    that caches one of them (PRT entries are cached once looked at) answers for the whole fragment, backed slots included:
+    they read as zeros and swallow writes, for good (tools/prt_tlb_probe.cpp "neighbours": 255 of 256 backed slots). The
+    kernel rewrites those remainders at the next PRT operation of the process; a map batch makes one before its
+    invalidation (DrmVm::refresh_prt_remainders). Here: every 2nd / 3rd / 5th slot of a region backed and stamped, ALL
+    slots read chip-wide, the backed ones checked - in a child, and once more with the rewrite switched off by a hook,
+    where backed slots must come back wrong (the test has teeth)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, KVCACHED_LOG_LEVEL="ERROR", KVCACHED_PHYS_RESERVE_MB="0")
+    base.pop("KVCACHED_ZERO_BACKFILL", None)
+    ok = subprocess.run([sys.executable, "-c", _NEIGHBOUR_CHILD % repo], env=base, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "WRONG WORDS 0" in ok.stdout, (ok.stdout[-500:], ok.stderr[-1500:])
+    broken = subprocess.run([sys.executable, "-c", _NEIGHBOUR_CHILD % repo], env=dict(base, KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH="1"),
+                            capture_output=True, text=True, timeout=300)
+    assert broken.returncode == 0, broken.stderr[-1500:]
+    wrong = int(broken.stdout.split("WRONG WORDS")[1].split()[0])
+    assert wrong > 0, "without the rewrite of the split PRT mappings nothing was shadowed: the hook or the hazard is gone"
+
+
 def test_unmap_batches_with_runs_of_neighbours(vmm):
     """drm backend: an unmap batch is sorted and every run of adjacent slots goes in one ranged ioctl (<= 16 slots per
     call). Whatever the listing order, the run lengths or a slot listed twice: exactly the listed slots
