@@ -636,8 +636,8 @@ std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size
 // reservation; on ROCm hipMemUnmap of an alias costs O(aliases of that handle) (~6 ns each: 37 us
 // per slot at 6k aliases, 220-260 us at 32k, ~1 ms at the 147k slots of a 288 GiB reservation), so
 // the zero page is sharded: one handle per `fanout` slots (default 256 => 0.4 % of the VA size).
-// The rest state of unbacked slots on the drm backend where reads of them must not fault: PRT (DrmVm::map_prt), one ioctl
-// for the whole region. Default in compat mode. NOT in lazy mode: a PRT translation IS cached by the TLBs once something
+// The rest state of unbacked slots on the drm backend where reads of them must not fault: PRT (DrmVm::map_prt), one
+// mapping per group of 64 slots. Default in compat mode. NOT in lazy mode: a PRT translation IS cached by the TLBs once something
 // has looked at the address (tools/prt_tlb_probe.cpp: every read stale and 0.8 % of the writes lost after backing such
 // slots without an invalidation), so backing a PRT slot owes an invalidation before the page is used - and lazy mode's
 // contract (nothing touches unbacked VA) is what makes its map path free of one: plain unmapped VA, where a violation
