@@ -1517,35 +1517,18 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   sg.mark(12);
   size_t max_clear = (size_t)options().clear_run_slots.load();
   if (max_clear >= 2 && xpool->multi_page()) max_clear = std::max<size_t>(max_clear, xpool->max_extent_pages()); // a whole extent in one go
-  if (max_clear >= 2 && slots.size() >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
-    std::vector<uint32_t> order;
-    order.reserve(slots.size());
+  if (max_clear >= 2 && vmm_backend() == kVmmDrm && DrmVm::instance().can_clear()) {
+    RunScan scan; // (a slot listed twice: its second mention is logged as "not mapped" below)
     for (uint32_t i = 0; i < slots.size(); ++i) {
-      const KvRegion &r = *slots[i].region;
+      KvRegion &r = *slots[i].region;
       const uint8_t m = r.mapped[slots[i].index];
-      if (!r.backfilled && !r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index])))) order.push_back(i);
+      if (!r.backfilled && !r.rest_direct() && ((m == 1 && own_direct) || ((m == 1 || m == 2) && vmm_direct_bo(r.handle[slots[i].index]))))
+        if (scan.add(&r, slots[i].index)) cleared[i] = 1;
     }
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-      return slots[a].region != slots[b].region ? slots[a].region < slots[b].region : slots[a].index < slots[b].index;
-    });
-    for (size_t i = 1; i < order.size(); ++i) // the same slot listed twice (tolerated: logged and skipped below): no runs
-      if (slots[order[i]].region == slots[order[i - 1]].region && slots[order[i]].index == slots[order[i - 1]].index) {
-        order.clear();
-        break;
-      }
-    for (size_t i = 0; i < order.size();) {
-      size_t j = i + 1;
-      while (j < order.size() && j - i < max_clear && slots[order[j]].region == slots[order[i]].region &&
-             slots[order[j]].index == slots[order[j - 1]].index + 1)
-        ++j;
-      if (j - i >= 2) {
-        KvRegion &r = *slots[order[i]].region;
-        const int64_t t0 = now_ns();
-        vmm_unmap_run(r.base + slots[order[i]].index * ps, (j - i) * ps);
-        stats().t_unmap += now_ns() - t0;
-        for (size_t k = i; k < j; ++k) cleared[order[k]] = 1;
-      }
-      i = j;
+    for (const SlotRun &run : scan.collect([](const KvRegion &) { return (size_t)-1; }, max_clear)) {
+      const int64_t t0 = now_ns();
+      vmm_unmap_run(run.r->base + run.first * ps, run.count * ps);
+      stats().t_unmap += now_ns() - t0;
     }
   }
   for (size_t si = 0; si < slots.size(); ++si) {
