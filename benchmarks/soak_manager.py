@@ -152,8 +152,12 @@ def main():
             print(f"[soak] {int(t_end - time.time())} s to go, {counts['alloc']} allocs, {counts['blocks_verified']} blocks verified, "
                   f"{bad} wrong words", file=sys.stderr, flush=True)
         if args.touch_unbacked and n_ops % 32 == 0:
+            # every slot of every region, backed or not: alternately one word per slot (a one-workgroup kernel) and one word
+            # per 4 KiB (chip-wide: every XCD's TLBs get to see the unbacked neighbours of whatever is backed - the shape that
+            # tools/prt_tlb_probe.cpp needed to show what cached PRT entries do)
+            stride = PAGE // 8 if (n_ops // 32) % 2 else 512
             for w in words:
-                touched_sum += int(w[::PAGE // 8].sum())              # one word per 2 MiB slot, K half and V half alike
+                touched_sum += int(w[::stride].sum())
             counts["sweeps_over_every_slot"] = counts.get("sweeps_over_every_slot", 0) + 1
         if n_ops % 64 == 0:
             st_now = capi.get_stats()
@@ -172,7 +176,21 @@ def main():
                     free_one(next(iter(live)))
                 continue
             ids_t = torch.tensor(ids, dtype=torch.int64, device=dev)
-            sign(ids_t, next_rid)
+            if args.touch_unbacked and next_rid % 8 == 0:
+                # the window that only a map opens (until the next unmap the kernel has the remainders of the PRT mappings this
+                # alloc has split still queued): the unbacked neighbours are looked at chip-wide BEFORE the new
+                # blocks are written, and the blocks are read back at once
+                for w in words:
+                    touched_sum += int(w[::512].sum())
+                sign(ids_t, next_rid)
+                for w in words:
+                    touched_sum += int(w[::512].sum())
+                wnow = verify(ids_t, next_rid)
+                if wnow:
+                    bad += wnow
+                    print(f"[soak] request {next_rid}: {wnow} signature words wrong right after its alloc, over {len(ids)} blocks", file=sys.stderr)
+            else:
+                sign(ids_t, next_rid)
             live[next_rid] = (ids_t, ids)
             next_rid += 1
             counts["alloc"] += 1
