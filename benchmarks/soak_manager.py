@@ -37,7 +37,10 @@ def main():
                     help="every 32 ops a kernel reads one word of EVERY slot of every region, backed or not (needs a mode in which "
                          "unbacked VA does not fault: PRT or zero aliases): if a PRT 'miss' were ever cached by the GPU, a slot "
                          "backed afterwards would be shadowed by it and its signatures would come back wrong")
+    ap.add_argument("--no-prt", action="store_true", help="compat mode with the zero extent behind unbacked VA instead of PRT (KVCACHED_PRT=false)")
     args = ap.parse_args()
+    if args.no_prt:
+        os.environ["KVCACHED_PRT"] = "false"
     if args.pool_mb is not None:
         os.environ["KVCACHED_PHYS_POOL_MB"] = str(args.pool_mb)
     if args.extent_pages is not None:
