@@ -166,6 +166,9 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
         ready = [batch_offsets((warmup + i) % window, slot=slot) for i in range(steps)]
         if fanout is None:
             ready = [capi.i64_array(o) for o in ready]
+        else:
+            import numpy as np
+            ready = [np.asarray(o, dtype=np.int64) for o in ready]   # packed into the broadcast message with one copy
         t0 = time.perf_counter()
         for i in range(steps):
             offs = ready[i]
