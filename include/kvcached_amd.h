@@ -122,7 +122,12 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              as it is (no driver call, zero-filled again). The caller's free() path drops from
  *                              ~15 us per slot to a queue push; queued bytes count as free in kvc_mem_get_info.
  *                              kvc_flush_unmaps() waits for the queue (trim/resize/shutdown do it themselves).
- *                              0 (default) = synchronous, like the reference. Ignored in compat mode. */
+ *                              0 (default) = synchronous, like the reference. Ignored in compat mode.
+ * Read-only diagnostics through kvc_get_option (numbers >= 100; kvcached_amd/capi.py names them): 108 backend in effect,
+ * 110 pages straight from KFD, 111 invalidations done off the callers' threads, 112-117 page creation / release time
+ * split, 118 the KFD ioctl pair is the invalidation in use, 119 pages per extent at most, 120-124 the extent pool's
+ * footprint, 125/126 pages zeroed on their way back / handed out without a fill of their own, 127 pages of the zero
+ * extent, 128 PRT behind unbacked VA, 130-149 host nanoseconds of the map / unmap calls by segment (bench.py). */
 enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
        KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6, KVC_OPT_ASYNC_UNMAP = 7 };
 int kvc_set_option(int opt, int64_t value);

@@ -37,7 +37,8 @@ OPT_POOL_HELD_PAGES, OPT_POOL_OUT_PAGES, OPT_POOL_FREE_PIECES, OPT_POOL_EXTENT_P
 # read-only: pages zeroed on their way back to the pool / handed out by map calls that had nothing left to zero (§4.9)
 OPT_PAGES_SCRUBBED, OPT_PAGES_PRESCRUBBED = 125, 126
 OPT_ZERO_EXTENT_PAGES = 127  # read-only: compat mode aliases a zero extent of this many pages (0: PRT, or sharded zero pages through ROCr)
-OPT_PRT = 128                # read-only: unbacked slots are PRT mappings (reads 0, writes dropped, no fault; either mode)
+OPT_PRT = 128                # read-only: unbacked slots are PRT mappings (reads 0, writes dropped, no fault): the compat default on drm/gfx950
+OPT_HOST_SEGMENT_0 = 130     # read-only, 130..149: host ns of the map/unmap calls by segment since the last reset (bench.py HOST_SEGMENTS)
 
 _vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 _I64P = ctypes.POINTER(ctypes.c_int64)
