@@ -51,8 +51,9 @@ inline uint32_t kfd_gpu_id_of_hip_device(int hip_dev) {
 // reached it through hipMalloc(2 MiB) + hipFree and watched the clock to guess whether the runtime had served the block
 // from a cache. This is the ioctl pair itself, on a 4 KiB buffer of our own at a VA nothing else will ever use, on our
 // own fd of /dev/kfd (every open of /dev/kfd by a process attaches to the same kfd_process, so it is ROCr's address
-// space): AMDKFD_IOC_MAP_MEMORY_TO_GPU + AMDKFD_IOC_UNMAP_MEMORY_FROM_GPU. No user-space cache can answer it; it costs
-// what the flush costs (170-200 us, tools/drm_vmm_probe.cpp mode 1: 0 wrong words where no flush gives all wrong).
+// space): AMDKFD_IOC_UNMAP_MEMORY_FROM_GPU + AMDKFD_IOC_MAP_MEMORY_TO_GPU (in that order: see flush()). No user-space
+// cache can answer it; it costs what the flush costs (0.18-0.24 ms; tools/drm_vmm_probe.cpp mode 1: 0 wrong words where
+// no flush gives all wrong).
 class KfdTlbFlush {
 public:
   KfdTlbFlush() = default;
