@@ -91,6 +91,7 @@ GpuContext::~GpuContext() {
   zero_extents_.clear();
   for (auto &a : arenas_) (void)hipMemAddressFree(a.base, a.size);
   arenas_.clear();
+  if (fallback_block_) (void)hipFree(fallback_block_);
   if (scrub_stream_) (void)hipStreamDestroy(scrub_stream_);
   for (auto &e : scrub_events_) (void)hipEventDestroy(e.second);
   for (auto ev : scrub_free_events_) (void)hipEventDestroy(ev);
@@ -652,18 +653,27 @@ void GpuContext::do_shootdown() {
     stats().seg[19] += map_ns; // (diagnostics, option 149: the re-MAP half of the pair; the UNMAP half is the flush itself)
   } else {
     // Fallback where /dev/kfd cannot be driven directly: an allocation that reaches KFD. 2 MiB is the smallest size
-    // ROCr does not serve from its sub-allocator (measured: 4 KiB has no effect, 2 MiB ~0.22 ms). A real trip to the
-    // kernel takes >150 us on MI355X; one that returns in <20 us was served from a cache and invalidated nothing, so a
-    // block too large for any cache is used instead. (Only this fallback watches the clock; init's self test has
-    // checked that it invalidates at all.)
-    void *p = nullptr;
-    HIP_CHECK(hipMalloc(&p, 2u << 20));
+    // ROCr does not serve from its sub-allocator (measured: 4 KiB has no effect). What invalidates is the FREE (KFD's
+    // unmap ends in the heavyweight flush); the allocation's map ends in a flush of its own when the address space has
+    // changed since KFD last flushed - so, as with the ioctl pair (KfdTlbFlush::flush), a block is kept in hand: the
+    // invalidation is its hipFree, and the hipMalloc of the next one right behind it finds nothing new to flush for.
+    // A real trip to the kernel takes >150 us on MI355X; a hipFree that returns in <20 us was answered from a cache and
+    // invalidated nothing, so a block too large for any cache is used instead. (Only this fallback watches the clock;
+    // init's self test has checked that it invalidates at all.)
+    if (!fallback_block_) HIP_CHECK(hipMalloc(&fallback_block_, 2u << 20));
+    const int64_t t1 = now_ns();
+    void *p = fallback_block_;
+    fallback_block_ = nullptr;
     HIP_CHECK(hipFree(p));
-    if (now_ns() - t0 < 20000) {
+    if (now_ns() - t1 < 20000) {
       static std::atomic<bool> warned{false};
-      if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: 2 MiB allocation did not reach the driver; using 64 MiB blocks");
+      if (!warned.exchange(true)) KVC_LOG(LOG_WARNING, "TLB shootdown: freeing a 2 MiB allocation did not reach the driver; using 64 MiB blocks");
       HIP_CHECK(hipMalloc(&p, 64u << 20));
       HIP_CHECK(hipFree(p));
+    }
+    if (hipMalloc(&fallback_block_, 2u << 20) != hipSuccess) { // (for the next one; without it that one allocates first)
+      (void)hipGetLastError();
+      fallback_block_ = nullptr;
     }
   }
   done.ok = true;

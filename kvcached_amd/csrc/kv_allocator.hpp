@@ -196,6 +196,7 @@ private:
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
   std::vector<ExtentPool *> all_pools();
   KfdTlbFlush kfd_flush_;
+  void *fallback_block_ = nullptr; // the 2 MiB allocation whose hipFree is the next invalidation of the hipMalloc/hipFree fallback
   hipStream_t scrub_stream_ = nullptr;
   std::mutex scrub_mu_; // launch order = ticket order
   std::atomic<uint64_t> scrub_issued_{0}, scrub_done_{0};
