@@ -165,6 +165,10 @@ int64_t kvc_get_option(int opt) {
   case 130: case 131: case 132: case 133: case 134: case 135: case 136: case 137: case 138: case 139:
   case 140: case 141: case 142: case 143: case 144: case 145: case 146: case 147: case 148: case 149:
     return stats().seg[opt - 130];
+  // 150..161: more of the same. 150 map: rewrite of split PRT / zero-extent remainders (a share of 136), 151 map: page-table
+  // ioctls issued (a count), 152 unmap: page-table ioctls issued (a count), 153 map: runs of adjacent slots (a count)
+  case 150: case 151: case 152: case 153: case 154: case 155: case 156: case 157: case 158: case 159: case 160: case 161:
+    return stats().seg[opt - 130];
   case 118: { // the direct KFD TLB flush is what tlb_shootdown() uses (read-only)
     GpuContext *ctx = KvAllocator::gpu();
     return ctx && ctx->kfd_flush_active() ? 1 : 0;

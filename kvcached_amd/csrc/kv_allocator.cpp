@@ -1159,6 +1159,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   void *zx_dirty = nullptr; // compat mode, zero extent: its group mappings were split by this batch's REPLACEs (§4.8's hazard)
   bool prt_dirty = false;   // PRT mappings were split by this batch: what is left of them carries fragments that span the new pages
   auto flush_for_batch = [&]() {
+    const int64_t t_rw = now_ns();
     if (prt_dirty) { // rewritten before the invalidation that covers them (DrmVm::refresh_prt_remainders)
       if (!env_bool("KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH", false) && !DrmVm::instance().refresh_prt_remainders()) // (hook: prove the test has teeth)
         throw GpuError("rewriting the remainders of split PRT mappings failed");
@@ -1172,6 +1173,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
       need_epoch = ctx->next_flush_epoch();
       zx_dirty = nullptr;
     }
+    stats().seg[20] += now_ns() - t_rw;
     if (blanket || always_flush)
       ctx->ensure_flushed();
     else
@@ -1329,6 +1331,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     if (fresh.size()) {
       std::vector<Phys> got(kMaxExtentPages);
       const std::vector<SlotRun> runs = fresh.collect();
+      stats().seg[23] += (int64_t)runs.size();
       sg.mark(2);
       for (const SlotRun &run : runs) {
         KvRegion &r = *run.r;
@@ -1367,6 +1370,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           }
           stats().t_acquire += t2 - t1;
           stats().t_map += now_ns() - t2;
+          stats().seg[21]++;
           sg.mark(4);
           for (size_t k = 0; k < n; ++k) {
             const size_t index = at + k;
@@ -1506,6 +1510,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
       const int rc = rest_replace(*run.r, run.first, run.count);
       if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the rest state) failed: ") + strerror(rc < 0 ? -rc : rc));
       stats().t_unmap += now_ns() - t0;
+      stats().seg[22]++;
       // the extents these pages belong to, in address order: neighbours share theirs, so the list stays short
       if (own_direct)
         for (size_t k = run.first; k < run.first + run.count; ++k) {

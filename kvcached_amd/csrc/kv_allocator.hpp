@@ -62,7 +62,7 @@ struct Stats {
   // host time inside each driver call of the map/unmap paths (diagnostics; kvc_get_driver_breakdown)
   std::atomic<int64_t> t_unmap_alias{0}, t_acquire{0}, t_map{0}, t_access{0}, t_unmap{0}, t_release{0}, t_realias{0}, t_sync{0};
   // host time of the map / unmap calls by segment (diagnostics, read-only options 130 + i; names in c_api.cpp)
-  std::atomic<int64_t> seg[20] = {};
+  std::atomic<int64_t> seg[32] = {};
   std::mutex mu;
   double fill_ms = 0, compact_ms = 0;
   VmmCounters vmm;
