@@ -19,6 +19,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libkvcached_amd.so")
+# The same library with the test hooks compiled in (-DKVC_TEST_HOOKS: switches that remove a safety step so that the tests can
+# show they would notice). Never loaded by the product: only child processes of the tests that ask for it by path
+# (KVCACHED_AMD_LIBRARY + LD_LIBRARY_PATH, tests/kvc_testlib.py: hooks_env()).
+HOOKS_DIR = os.path.join(HERE, "_testhooks")
+HOOKS_LIB = os.path.join(HOOKS_DIR, "libkvcached_amd.so")
 EXT = os.path.join(HERE, "vmm_ops" + sysconfig.get_config_var("EXT_SUFFIX"))
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
@@ -26,7 +31,7 @@ ARCH = "gfx950"
 
 LIB_SRCS = ["c_api.cpp", "kv_allocator.cpp", "gpu_context.cpp", "page_allocator.cpp", "kernels.hip", "index_kernels.hip"]
 LIB_DEPS = LIB_SRCS + ["common.hpp", "hip_vmm.hpp", "drm_vm.hpp", "extent_pool.hpp", "kernels.hpp", "kv_allocator.hpp", "mem_info.hpp",
-                       "page_allocator.hpp", "../../include/kvcached_amd.h"]
+                       "page_allocator.hpp", "run_scan.hpp", "../../include/kvcached_amd.h"]
 EXT_SRCS = ["vmm_ops.cpp"]
 
 
@@ -43,12 +48,14 @@ def _run(cmd):
 
 
 def build_lib(force: bool = False) -> str:
-    if force or _stale(LIB, LIB_DEPS):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-result", "-x", "hip"]
-        cmd += [os.path.join(CSRC, s) for s in LIB_SRCS]
-        cmd += ["-o", LIB, f"-L{os.path.join(ROCM, 'lib')}", "-lhsa-runtime64", "-ldl"]  # ROCr directly (hybrid/drm VMM backends); libdrm_amdgpu is dlopen()ed
-        _run(cmd)
+    for target, extra in ((LIB, []), (HOOKS_LIB, ["-DKVC_TEST_HOOKS=1"])):
+        if force or _stale(target, LIB_DEPS):
+            os.makedirs(os.path.dirname(target), exist_ok=True)
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                   "-Wall", "-Wno-unused-result"] + extra + ["-x", "hip"]
+            cmd += [os.path.join(CSRC, s) for s in LIB_SRCS]
+            cmd += ["-o", target, f"-L{os.path.join(ROCM, 'lib')}", "-lhsa-runtime64", "-ldl"]  # ROCr directly (hybrid/drm VMM backends); libdrm_amdgpu is dlopen()ed
+            _run(cmd)
     return LIB
 
 

@@ -12,7 +12,9 @@ import os
 from typing import List, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkvcached_amd.so")
+# KVCACHED_AMD_LIBRARY: the tests' build with hooks compiled in (kvcached_amd/_testhooks/, see build.py) - an explicit path,
+# never a fallback: the library named must exist.
+LIB_PATH = os.environ.get("KVCACHED_AMD_LIBRARY") or os.path.join(_HERE, "libkvcached_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `python -m kvcached_amd.build` "

@@ -174,21 +174,15 @@ int64_t kvc_get_option(int opt) {
     return ctx && ctx->kfd_flush_active() ? 1 : 0;
   }
   case 119: return options().phys_chunk_pages; // pages per extent at most (read-only; KVCACHED_PHYS_CHUNK_PAGES at init)
-  case 120: { // pool footprint: pages held from the driver (read-only, 120-123)
+  case 120: case 121: case 122: case 123: { // footprint of the pool the engine's pages come from, in pages: held from the driver,
+    // handed out, free inside partly used buffers (the waste), and the size new buffers get right now (read-only)
     GpuContext *ctx = KvAllocator::gpu();
-    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().held_pages : 0;
-  }
-  case 121: {
-    GpuContext *ctx = KvAllocator::gpu();
-    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().out_pages : 0;
-  }
-  case 122: {
-    GpuContext *ctx = KvAllocator::gpu();
-    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().free_pieces : 0;
-  }
-  case 123: {
-    GpuContext *ctx = KvAllocator::gpu();
-    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().extent_pages_now : 0;
+    if (!ctx) return 0;
+    ExtentPool *p = ctx->primary_pool();
+    if (!p) return opt == 123 ? (int64_t)options().phys_chunk_pages.load() : 0; // (nothing mapped yet: no pool is made for a diagnostic)
+    const auto f = p->footprint();
+    const int64_t scale = (int64_t)p->counter_scale();
+    return scale * (int64_t)(opt == 120 ? f.held_pages : opt == 121 ? f.out_pages : opt == 122 ? f.free_pieces : f.extent_pages_now);
   }
   case 127: { // pages of the zero extent behind compat-mode regions (0: none - PRT, or sharded zero pages through ROCr; read-only)
     GpuContext *ctx = KvAllocator::gpu();
@@ -205,7 +199,15 @@ int64_t kvc_get_option(int opt) {
   case 126: return stats().pages_prescrubbed; // pages a map call handed out without launching a fill for them
   case 124: { // releases of pieces the pool did not know (must stay 0; read-only)
     GpuContext *ctx = KvAllocator::gpu();
-    return ctx ? (int64_t)ctx->extents(KvAllocator::page_size(), false)->footprint().bad_releases : 0;
+    ExtentPool *p = ctx ? ctx->primary_pool() : nullptr;
+    return p ? (int64_t)p->footprint().bad_releases : 0;
+  }
+  case 129: { // page ids of group 0 are backed as units (lanes: DESIGN.md §4.11), and how many lanes a buffer holds at most (0: no; read-only)
+    try {
+      return KvAllocator::initialized() ? (int64_t)KvAllocator::global(0)->lanes_per_extent() : 0;
+    } catch (...) {
+      return 0;
+    }
   }
   case 104: return fail_after_creates();
   case 100: return options().fill_variant;

@@ -85,6 +85,30 @@ inline bool env_bool(const char *name, bool dflt) {
   return s == "1" || s == "true" || s == "yes" || s == "on";
 }
 
+// Test hooks: switches that REMOVE a safety step (the TLB invalidation, the rewrite of split mappings, a self test) so that
+// the tests can show they would notice. They exist only in the build the tests load for that purpose (-DKVC_TEST_HOOKS,
+// kvcached_amd/_testhooks/libkvcached_amd.so); the shipped library contains neither the code nor the names.
+#ifdef KVC_TEST_HOOKS
+inline bool test_hook_on(const char *name) {
+  const bool on = env_bool(name, false);
+  if (on) {
+    static const char *reported[16] = {};
+    for (auto &r : reported) {
+      if (r == name) break; // (string literals: one address per call site is enough to keep the log short)
+      if (!r) {
+        r = name;
+        KVC_LOG(LOG_ERROR, "TEST HOOK %s is active: this library build removes safety steps on request and must never be deployed", name);
+        break;
+      }
+    }
+  }
+  return on;
+}
+#define KVC_TEST_HOOK(name) ::kvc::test_hook_on("KVCACHED_TEST_" name)
+#else
+#define KVC_TEST_HOOK(name) false
+#endif
+
 // "cuda", "cuda:N", "hip[:N]" -> gpu index (-1 = current device); "cpu" -> is_gpu=false.
 struct DeviceSpec {
   bool is_gpu = false;

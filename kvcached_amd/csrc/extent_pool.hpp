@@ -114,12 +114,14 @@ struct ExtentDriver {
 
 class ExtentPool {
 public:
-  ExtentPool(size_t page_bytes, unsigned max_extent_pages, ExtentDriver drv, VmmCounters *ctr)
+  // `ctr_scale`: what one unit of this pool counts for in the counters (a pool of lanes: the pages of a lane)
+  ExtentPool(size_t page_bytes, unsigned max_extent_pages, ExtentDriver drv, VmmCounters *ctr, size_t ctr_scale = 1)
       : page_bytes_(page_bytes), kmax_cfg_(std::min(std::max(max_extent_pages, 1u), kMaxExtentPages)), kmax_cur_(kmax_cfg_),
-        drv_(std::move(drv)), ctr_(ctr) {}
+        drv_(std::move(drv)), ctr_(ctr), scale_(ctr_scale ? ctr_scale : 1) {}
   ~ExtentPool() { drain(0); }
 
   size_t page_bytes() const { return page_bytes_; }
+  size_t counter_scale() const { return scale_; }
   unsigned max_extent_pages() const { return kmax_cfg_; }
   bool multi_page() const { return kmax_cfg_ > 1; }
   unsigned current_extent_pages() {
@@ -178,8 +180,7 @@ public:
     e.ticket = 0;
     free_pieces_ += n;
     held_pages_ += n;
-    ctr_->created += n;
-    last_created_pages_ = n;
+    ctr_->created += n * scale_;
     ++creations_;
     return take_pieces_locked(h, e, 0, n, out, recycled);
   }
@@ -196,6 +197,13 @@ public:
       have += out[i] != 0;
     }
     return have;
+  }
+
+  // the alias address of the buffer a handle is a piece of (0: none, or unknown)
+  uint64_t tag_of(phys_handle_t h) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = tracked_.find(key_of(h));
+    return it == tracked_.end() ? 0 : it->second.tag;
   }
 
   void release(Phys p) { release_batch(&p, 1); }
@@ -323,7 +331,11 @@ public:
   // Pre-create clean extents (never used: nothing to wipe, nothing to hide) until `target_pages` are idle, at most
   // `max_pages` per call: a growth burst then finds memory the kernel has already cleared. Allocating VRAM that has not
   // been handed out since boot costs ~80 us per 2 MiB (the kernel clears it on one SDMA ring at ~30 GB/s,
-  // profiles/r02_create_cost.jsonl) against 1.8 us for memory that was wiped on release. Sizes follow the last on-demand creation.
+  // profiles/r02_create_cost.jsonl) against 1.8 us for memory that was wiped on release. The reserve is made of extents of
+  // the LARGEST size in use right now (the governor's): a run of any length up to that is then served out of one of them with
+  // one ioctl per run - and what it leaves over is handed out before anything else (acquire_run's second preference) -
+  // whereas a reserve shaped like whatever happened to be created first (single pages, say) turns every later run into as
+  // many ioctls as it has pages (profiles/r03_engine_geometry_before_lanes_compat.jsonl: 512 ioctls for 8 page ids).
   size_t refill_reserve(size_t target_pages, size_t max_pages) {
     size_t made = 0;
     while (made < max_pages) {
@@ -331,8 +343,7 @@ public:
       {
         std::lock_guard<std::mutex> g(mu_);
         if (idle_pages_ + free_pieces_ >= target_pages) break;
-        n = std::min<unsigned>(std::max(1u, last_created_pages_), kmax_cur_);
-        n = (unsigned)std::min<size_t>(n, target_pages - idle_pages_ - free_pieces_);
+        n = (unsigned)std::min<size_t>(kmax_cur_, target_pages - idle_pages_ - free_pieces_);
       }
       if (drv_.under_pressure && drv_.under_pressure()) break;
       phys_handle_t h;
@@ -344,7 +355,7 @@ public:
       }
       std::lock_guard<std::mutex> g(mu_);
       held_pages_ += n;
-      ctr_->created += n;
+      ctr_->created += n * scale_;
       idle_insert_locked(h, IdleInfo{++next_seq_, (uint8_t)n, false, tag, 0, 0});
       made += n;
     }
@@ -447,7 +458,7 @@ private:
     free_pieces_ -= n;
     out_pieces_ += n;
     handed_out_since_clamp_ += n;
-    ctr_->reused += old;
+    ctr_->reused += old * scale_;
     *recycled = old > 0;
     rebucket_locked(h, e);
     govern_locked();
@@ -529,7 +540,7 @@ private:
     size_t pages = 0;
     for (auto &p : v) {
       if (!drv_.release(p.h)) ++failed_releases_;
-      ctr_->released += p.n;
+      ctr_->released += p.n * scale_;
       pages += p.n;
     }
     std::lock_guard<std::mutex> g(mu_);
@@ -541,12 +552,12 @@ private:
   unsigned kmax_cur_;
   ExtentDriver drv_;
   VmmCounters *ctr_;
+  const size_t scale_;
   std::atomic<size_t> cap_pages_{0};
   std::atomic<double> waste_frac_{0.05};
   std::atomic<bool> defer_eviction_{false};
   std::mutex mu_;
   uint64_t next_seq_ = 0, idle_stamp_ = 0;
-  unsigned last_created_pages_ = 1;
   std::atomic<size_t> creations_{0}; // extents created on demand (not for the reserve)
   size_t handed_out_since_clamp_ = 0;
   size_t recover_pages_ = 4096; // 8 GiB of 2 MiB pages handed out between two steps back up

@@ -82,8 +82,10 @@ GpuContext::~GpuContext() {
     (void)hipEventDestroy(e.second);
   }
   if (scrub_stream_) (void)hipStreamSynchronize(scrub_stream_); // no fill may be running on an alias that is about to go
+  primary_pool_.store(nullptr);
   extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
   extent_pools_[1].clear();
+  lane_pools_.clear();
   for (auto &kv : zero_extents_) {
     (void)DrmVm::instance().clear(reinterpret_cast<void *>(kv.second.alias), kv.second.pages * kv.first);
     (void)DrmVm::instance().forget(kv.second.h);
@@ -120,6 +122,58 @@ bool device_under_pressure() {
 }
 } // namespace
 
+// What a pool creates and releases its buffers with. `unit_bytes`: bytes of one unit of the pool (a page; a lane).
+ExtentDriver GpuContext::make_driver(size_t unit_bytes, bool exportable, bool aliases) {
+  ExtentDriver d;
+  const int dev = dev_;
+  d.create = [this, dev, unit_bytes, exportable, aliases](size_t units, uint64_t *tag) -> phys_handle_t {
+    if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
+      hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
+    const phys_handle_t h = vmm_create(dev, units * unit_bytes, exportable, true, (unsigned)units);
+    if (tag) *tag = 0;
+    if (tag && aliases) {
+      // The buffer's second, permanent mapping: the address its pages are zeroed through after their slots are gone.
+      // One more ioctl per buffer; failure only means that its pages are zeroed when they are mapped, as before.
+      if (void *bo = DrmVm::instance().find(h)) {
+        const uint64_t va = alias_alloc(units * unit_bytes);
+        if (va && DrmVm::instance().map(bo, reinterpret_cast<void *>(va), units * unit_bytes, 0) == 0)
+          *tag = va;
+        else if (va)
+          alias_free(va, units * unit_bytes);
+      }
+    }
+    return h;
+  };
+  d.prepare_release = [this, unit_bytes](phys_handle_t, uint64_t tag, size_t units) {
+    if (!tag) return;
+    wait_all_scrubs(); // nothing may still be writing through the alias
+    StaleAfter mark;   // a live translation goes away: the invalidation before_release performs covers it
+    if (DrmVm::instance().clear(reinterpret_cast<void *>(tag), units * unit_bytes) != 0)
+      KVC_LOG(LOG_ERROR, "dropping the alias mapping of a buffer failed");
+    // the address is on offer again only AFTER the invalidation below: a new buffer mapped there earlier could have its
+    // scrub go through a cached translation of the old one
+    std::lock_guard<std::mutex> g(arena_mu_);
+    alias_limbo_.emplace_back(tag, units * unit_bytes);
+  };
+  d.release = [](phys_handle_t h) {
+    const bool ok = vmm_try_release(h);
+    if (!ok) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
+    (void)hipGetLastError();
+    return ok;
+  };
+  d.before_release = [this]() { // memory leaves the process: no translation of it may survive
+    std::vector<std::pair<uint64_t, size_t>> mine;
+    {
+      std::lock_guard<std::mutex> g(arena_mu_);
+      mine.swap(alias_limbo_); // (what another thread adds from here on is covered by ITS invalidation, not by this one)
+    }
+    flush_deferred_shootdown(); // (an invalidation that failed has raised the flag again: do_shootdown)
+    for (auto &a : mine) alias_free(a.first, a.second);
+  };
+  d.under_pressure = device_under_pressure;
+  return d;
+}
+
 ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
   // Run-sized extents need a map offset (GEM_VA has one; HIP rejects it, ROCr ignores it), ranged unmaps and buffers of
   // our own making: the drm backend with pages straight from KFD. Everything else works with single pages.
@@ -127,66 +181,58 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
   if (!exportable && vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && DrmVm::instance().can_clear())
     k = (unsigned)std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, options().phys_chunk_pages.load()));
   k = (unsigned)std::min<size_t>(k, std::max<size_t>(1, (256u << 20) / page_bytes)); // no buffer above 256 MiB (8 MiB pages, compound pages)
-  std::lock_guard<std::mutex> g(mu_);
-  auto &m = extent_pools_[exportable ? 1 : 0];
-  auto it = m.find(page_bytes);
-  if (it == m.end() || it->second->max_extent_pages() != k) {
-    // (re)made at the first use after an init that changed the extent size: no region exists then, every piece is home
-    ExtentDriver d;
-    const int dev = dev_;
-    const bool aliases = k > 1 && options().scrub_on_release.load() != 0; // (k > 1: drm backend, buffers of our own making)
-    d.create = [this, dev, page_bytes, exportable, aliases](size_t pages, uint64_t *tag) -> phys_handle_t {
-      if (fail_after_creates().load() >= 0 && fail_after_creates().fetch_sub(1) == 0) // fault injection (tests)
-        hip_check(hipErrorOutOfMemory, "hipMemCreate(&p.h, granule_, &prop, 0) [injected]", __FILE__, __LINE__);
-      const phys_handle_t h = vmm_create(dev, pages * page_bytes, exportable, true, (unsigned)pages);
-      if (tag) *tag = 0;
-      if (tag && aliases) {
-        // The buffer's second, permanent mapping: the address its pages are zeroed through after their slots are gone.
-        // One more ioctl per buffer; failure only means that its pages are zeroed when they are mapped, as before.
-        if (void *bo = DrmVm::instance().find(h)) {
-          const uint64_t va = alias_alloc(pages * page_bytes);
-          if (va && DrmVm::instance().map(bo, reinterpret_cast<void *>(va), pages * page_bytes, 0) == 0)
-            *tag = va;
-          else if (va)
-            alias_free(va, pages * page_bytes);
-        }
+  std::unique_ptr<ExtentPool> old; // destroyed (drained) after mu_ is released: ~ExtentPool waits for scrubs, whose harvest takes mu_
+  ExtentPool *p;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto &m = extent_pools_[exportable ? 1 : 0];
+    auto it = m.find(page_bytes);
+    if (it == m.end() || it->second->max_extent_pages() != k) {
+      // (re)made at the first use after an init that changed the extent size: no region exists then, every piece is home
+      if (housekeepers_.load() > 0 && it != m.end())
+        throw InvalidError("the extent size cannot change while a PageAllocator's housekeeping thread is alive: delete the PageAllocator first");
+      const bool aliases = k > 1 && options().scrub_on_release.load() != 0; // (k > 1: drm backend, buffers of our own making)
+      if (it != m.end()) {
+        if (primary_pool_.load() == it->second.get()) primary_pool_.store(nullptr);
+        old = std::move(it->second);
       }
-      return h;
-    };
-    d.prepare_release = [this, page_bytes](phys_handle_t, uint64_t tag, size_t pages) {
-      if (!tag) return;
-      wait_all_scrubs(); // nothing may still be writing through the alias
-      StaleAfter mark;   // a live translation goes away: the invalidation before_release performs covers it
-      if (DrmVm::instance().clear(reinterpret_cast<void *>(tag), pages * page_bytes) != 0)
-        KVC_LOG(LOG_ERROR, "dropping the alias mapping of a buffer failed");
-      // the address is on offer again only AFTER the invalidation below: a new buffer mapped there earlier could have its
-      // scrub go through a cached translation of the old one
-      std::lock_guard<std::mutex> g(arena_mu_);
-      alias_limbo_.emplace_back(tag, pages * page_bytes);
-    };
-    d.release = [](phys_handle_t h) {
-      const bool ok = vmm_try_release(h);
-      if (!ok) KVC_LOG(LOG_ERROR, "releasing a physical handle failed");
-      (void)hipGetLastError();
-      return ok;
-    };
-    d.before_release = [this]() { // memory leaves the process: no translation of it may survive
-      std::vector<std::pair<uint64_t, size_t>> mine;
-      {
-        std::lock_guard<std::mutex> g(arena_mu_);
-        mine.swap(alias_limbo_); // (what another thread adds from here on is covered by ITS invalidation, not by this one)
-      }
-      flush_deferred_shootdown();
-      for (auto &a : mine) alias_free(a.first, a.second);
-    };
-    d.under_pressure = device_under_pressure;
-    m[page_bytes] = std::make_unique<ExtentPool>(page_bytes, k, std::move(d), &stats().vmm);
-    it = m.find(page_bytes);
-    it->second->set_defer_eviction(housekeepers_.load() > 0);
+      m[page_bytes] = std::make_unique<ExtentPool>(page_bytes, k, make_driver(page_bytes, exportable, aliases), &stats().vmm);
+      it = m.find(page_bytes);
+      it->second->set_defer_eviction(housekeepers_.load() > 0);
+    }
+    p = it->second.get();
   }
-  it->second->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
-  it->second->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
-  return it->second.get();
+  old.reset();
+  p->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  p->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
+  return p;
+}
+
+ExtentPool *GpuContext::lane_extents(size_t rows, size_t page_bytes) {
+  if (rows < 2 || vmm_backend() != kVmmDrm || !DrmVm::instance().kfd_ready() || !DrmVm::instance().can_clear()) return nullptr;
+  const size_t lane_bytes = rows * page_bytes;
+  // lanes per buffer: as many as fit KVCACHED_LANE_EXTENT_MB (default 1024: 8 page ids of the Llama-3-8B geometry, 128 MiB each)
+  const size_t cap_b = (size_t)std::max<int64_t>(1, env_i64("KVCACHED_LANE_EXTENT_MB", 1024)) << 20;
+  const unsigned k = (unsigned)std::min<size_t>(kMaxExtentPages, std::max<size_t>(1, cap_b / lane_bytes));
+  std::unique_ptr<ExtentPool> old;
+  ExtentPool *p;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto &slot = lane_pools_[{rows, page_bytes}];
+    if (!slot || slot->max_extent_pages() != k) {
+      if (housekeepers_.load() > 0 && slot)
+        throw InvalidError("the lane extent size cannot change while a PageAllocator's housekeeping thread is alive");
+      if (slot && primary_pool_.load() == slot.get()) primary_pool_.store(nullptr);
+      old = std::move(slot);
+      slot = std::make_unique<ExtentPool>(lane_bytes, k, make_driver(lane_bytes, false, options().scrub_on_release.load() != 0), &stats().vmm, rows);
+      slot->set_defer_eviction(housekeepers_.load() > 0);
+    }
+    p = slot.get();
+  }
+  old.reset();
+  p->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  p->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
+  return p;
 }
 
 std::vector<ExtentPool *> GpuContext::all_pools() {
@@ -194,6 +240,8 @@ std::vector<ExtentPool *> GpuContext::all_pools() {
   std::vector<ExtentPool *> ps;
   for (auto &m : extent_pools_)
     for (auto &kv : m) ps.push_back(kv.second.get());
+  for (auto &kv : lane_pools_)
+    if (kv.second) ps.push_back(kv.second.get());
   return ps;
 }
 
@@ -232,17 +280,22 @@ void GpuContext::housekeeping() {
   // Releasing memory the GPU has touched costs 50-70 us per 2 MiB (the kernel wipes it) and driver calls of one
   // process do not overlap: 256 pages per 100 ms tick keeps this thread's share of the driver under ~15 % while
   // still returning 5 GiB/s.
-  constexpr size_t kPerTick = 256;
-  for (auto *p : ps) p->trim_to_cap(kPerTick); // what release_batch left above the cap (deferred eviction)
+  constexpr size_t kPerTickBytes = 512u << 20; // (a pool's unit may be a lane of 128 MiB: the budget is in bytes)
+  auto per_tick = [&](ExtentPool *p) { return std::max<size_t>(1, kPerTickBytes / p->page_bytes()); };
+  for (auto *p : ps) p->trim_to_cap(per_tick(p)); // what release_batch left above the cap (deferred eviction)
   const int64_t idle_ms = options().pool_idle_ms.load();
-  const size_t reserve_b = (size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load());
+  // the reserve never exceeds the pool's cap (KVCACHED_PHYS_POOL_MB=0, "pool off", means no reserve either: what would be
+  // created here would be trimmed at the next tick, for ever)
+  const size_t reserve_b = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  ExtentPool *primary = primary_pool_.load();
   for (auto *p : ps) {
-    // the reserve belongs to the pool the engine's own pages come from (not to the exportable twin)
-    const size_t floor_pages = (p == ps[0] || ps.size() == 1) ? reserve_b / p->page_bytes() : 0;
-    if (idle_ms > 0) p->decay(now_ns(), idle_ms * 1000000ll, kPerTick, floor_pages);
+    // the reserve belongs to the pool the engine's own pages come from (recorded at its first map call), not to the
+    // exportable twin or to a pool a diagnostic happened to create
+    const size_t floor_pages = p == primary ? reserve_b / p->page_bytes() : 0;
+    if (idle_ms > 0) p->decay(now_ns(), idle_ms * 1000000ll, per_tick(p), floor_pages);
     // Growth into VRAM the kernel has not cleared yet costs ~80 us per 2 MiB inside the allocation (one SDMA ring,
     // ~30 GB/s: profiles/r02_create_cost.jsonl); this thread pays that ahead of time, off every caller's path.
-    if (floor_pages) p->refill_reserve(floor_pages, kPerTick);
+    if (floor_pages) p->refill_reserve(floor_pages, per_tick(p));
   }
 }
 
@@ -357,7 +410,7 @@ void GpuContext::wait_scrub(uint64_t ticket) {
         break;
       }
   }
-  static const bool whole_stream = env_bool("KVCACHED_TEST_SCRUB_WAIT_STREAM", false); // diagnostics: the previous behaviour
+  static const bool whole_stream = KVC_TEST_HOOK("SCRUB_WAIT_STREAM"); // diagnostics: the previous behaviour
   if (whole_stream) ev = nullptr;
   if (ev) {
     HIP_CHECK(hipEventSynchronize(ev)); // (should the event be recycled meanwhile, this waits for a later scrub: longer, never shorter)
@@ -634,14 +687,17 @@ void GpuContext::do_shootdown() {
     uint64_t e;
     bool ok = false;
     ~Done() {
-      if (ok) d.store(std::max(d.load(), e)); // (serialised by flush_mu_)
+      if (ok)
+        d.store(std::max(d.load(), e)); // (serialised by flush_mu_)
+      else
+        tlb_stale().store(true); // the flush threw: what it was to cover is still owed (flusher_loop and housekeeping only log)
     }
   } done{flush_done_, epoch};
   if (!options().tlb_shootdown.load()) {
     done.ok = true;
     return;
   }
-  static const bool broken_for_test = env_bool("KVCACHED_TEST_BREAK_TLB_FLUSH", false); // hook: the init self test must notice
+  static const bool broken_for_test = KVC_TEST_HOOK("BREAK_TLB_FLUSH"); // hook: the init self test must notice
   const int64_t t0 = now_ns();
   if (broken_for_test) {
     // nothing: what a runtime that stopped flushing would look like

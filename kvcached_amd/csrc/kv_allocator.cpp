@@ -48,7 +48,7 @@ GpuContext *context_for(int dev) {
 // mapped through ROCr, written with hipMemset and read back with hipMemcpy. Any surprise -> the plain HIP backend.
 namespace {
 bool hybrid_self_test(int dev) {
-  if (env_bool("KVCACHED_TEST_FAIL_HYBRID_SELFTEST", false)) return false; // tests: exercise the fallback
+  if (KVC_TEST_HOOK("FAIL_HYBRID_SELFTEST")) return false; // tests: exercise the fallback
   const size_t ps = kBasePage;
   void *va = nullptr;
   hipMemGenericAllocationHandle_t shell = nullptr;
@@ -97,7 +97,7 @@ bool hybrid_self_test(int dev) {
   { // the page was written through this VA: its translation must not outlive it (the page goes back below, and the
     // VA may be handed out again for a region whose first map no longer invalidates by itself)
     void *p = nullptr;
-    if (!env_bool("KVCACHED_TEST_SKIP_TEARDOWN_FLUSH", false) && hipMalloc(&p, kBasePage) == hipSuccess) (void)hipFree(p);
+    if (!KVC_TEST_HOOK("SKIP_TEARDOWN_FLUSH") && hipMalloc(&p, kBasePage) == hipSuccess) (void)hipFree(p);
     (void)hipGetLastError();
   }
   if (have_real) (void)hsa_amd_vmem_handle_release(real);
@@ -113,7 +113,7 @@ bool hybrid_self_test(int dev) {
 // unmapped it; this step touches no memory, so a wrong VM cannot fault - and (2) data follows the handle: two pages
 // swapped under one VA keep their own contents, seen through HIP's memset/copy on a HIP-registered slot.
 bool drm_self_test(int dev) {
-  if (env_bool("KVCACHED_TEST_FAIL_DRM_SELFTEST", false)) return false; // tests: exercise the fallback
+  if (KVC_TEST_HOOK("FAIL_DRM_SELFTEST")) return false; // tests: exercise the fallback
   std::string why;
   DrmVm &vm = DrmVm::instance();
   if (!vm.open(dev, &why)) {
@@ -185,7 +185,7 @@ bool drm_self_test(int dev) {
     if (vm.unmap(bo_b, va, ps) != 0) throw 23;
     drm_mapped = nullptr;
     bool kfd_ok = false;
-    if (env_bool("KVCACHED_DRM_KFD_CREATE", true) && !env_bool("KVCACHED_TEST_FAIL_KFD_SELFTEST", false)) {
+    if (env_bool("KVCACHED_DRM_KFD_CREATE", true) && !KVC_TEST_HOOK("FAIL_KFD_SELFTEST")) {
       std::string why_kfd;
       phys_handle_t k = 0;
       int step = 0;
@@ -510,12 +510,27 @@ KvAllocator::~KvAllocator() {
   }
   std::lock_guard<std::mutex> g(mu_);
   size_t still_queued = 0;
+  std::vector<Phys> lanes; // page ids still backed by lanes: their pages go home once every row is unmapped
+  if (lanes_ && !rows_.empty())
+    for (size_t p = 0; p < ids_per_row_; ++p) {
+      const size_t idx = rows_[0].first + p;
+      if (rows_[0].r->mapped[idx] == 4) lanes.push_back(Phys{rows_[0].r->handle[idx], rows_[0].r->seq[idx]});
+    }
   for (auto &r : layers_) {
     for (auto m : r->mapped) still_queued += (m == 3) ? r->page_size : 0;
     destroy_region(*r); // also unmaps what was still queued (state 3 counts as mapped there)
   }
   g_pending_unmap_bytes -= std::min(still_queued, g_pending_unmap_bytes.load());
   layers_.clear();
+  if (lane_pool_ && ctx_) {
+    try {
+      ctx_->ensure_flushed(); // (destroy_region has invalidated; a region that had nothing mapped owes nothing)
+    } catch (...) {
+      (void)hipGetLastError();
+    }
+    if (!lanes.empty()) lane_pool_->release_batch(lanes.data(), lanes.size());
+    lane_pool_->drain(0); // an allocator that goes away gives its memory back (the reference releases in ~FTensor, ftensor.cpp:78-98)
+  }
 }
 
 // ------------------------------------------------------------------ async unmap
@@ -862,7 +877,8 @@ void KvAllocator::destroy_region(KvRegion &r) {
     if (!whole) {
       if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
-    (r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
+    if (r.mapped[i] != 4) // (4: a page of a lane - the lane goes home once, from ~KvAllocator, not once per row)
+      (r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
   }
   std::sort(dead.begin(), dead.end(), [](const Phys &a, const Phys &b) { return a.seq < b.seq; }); // oldest first
@@ -870,7 +886,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
     for (size_t i = 0; i < r.num_slots(); ++i) (void)vmm_try_unmap(r.base + i * r.page_size, r.page_size);
   // Pages and zero pages leave the process and the VA range may be handed out again: no translation of either may
   // survive (any unmap above has set tlb_stale(); a region that never had anything mapped owes nothing).
-  if (ctx && tlb_stale().load() && !env_bool("KVCACHED_TEST_SKIP_TEARDOWN_FLUSH", false)) { // hook: prove the test has teeth
+  if (ctx && tlb_stale().load() && !KVC_TEST_HOOK("SKIP_TEARDOWN_FLUSH")) { // hook: prove the test has teeth
     try {
       ctx->tlb_shootdown();
     } catch (...) {
@@ -943,10 +959,12 @@ std::vector<KvAllocator::TensorDesc> KvAllocator::create_kv_tensors(size_t size,
     }
     for (auto &r : layers_) out.push_back({r->base, r->size});
   }
+  const bool first_time = num_layers_ == 0;
   num_layers_ = num_layers;
   num_kv_buffers_ = num_kv_buffers;
   unified_pool_ = unified_pool;
   tensor_bytes_per_layer_ = aligned;
+  if (first_time || contiguous_) setup_lanes();
   return out;
 }
 
@@ -958,6 +976,11 @@ bool KvAllocator::kv_tensors_created() {
 bool KvAllocator::uses_prt() {
   std::lock_guard<std::mutex> g(mu_);
   return !layers_.empty() && layers_[0]->prt;
+}
+
+size_t KvAllocator::lanes_per_extent() {
+  std::lock_guard<std::mutex> g(mu_);
+  return lanes_ && lane_pool_ ? lane_pool_->max_extent_pages() : 0;
 }
 
 std::vector<void *> KvAllocator::region_bases() {
@@ -1012,6 +1035,11 @@ bool KvAllocator::map_to_kv_tensors(const offset_t *offsets, size_t n) {
     return false;
   }
   SegTimer sg;
+  if (lanes_ && try_map_lanes(offsets, n)) { // page ids of a multi-row geometry: backed as units (lanes)
+    stats().map_calls++;
+    stats().map_ns += now_ns() - t0;
+    return true;
+  }
   const auto slots = slots_for(offsets, n);
   sg.mark(0);
   map_slots(slots, nullptr);
@@ -1030,6 +1058,18 @@ bool KvAllocator::unmap_from_kv_tensors(const offset_t *offsets, size_t n) {
     return false;
   }
   SegTimer sg;
+  std::vector<offset_t> others;
+  if (lanes_) { // page ids backed by lanes go back as units; whatever else the call names takes the generic path
+    (void)unmap_lanes(offsets, n, &others);
+    if (others.empty()) {
+      stats().unmap_calls++;
+      stats().unmap_ns += now_ns() - t0;
+      return true;
+    }
+    offsets = others.data();
+    n = others.size();
+    sg.t = now_ns();
+  }
   auto slots = slots_for(offsets, n);
   sg.mark(10);
   bool async = options().async_unmap.load() != 0; // also on the cpu device: same queue and thread, no driver calls
@@ -1126,6 +1166,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   ctx->bind();
   const size_t ps = slots[0].region->page_size;
   ExtentPool *pool = ctx->extents(ps, exportable_);
+  if (!exportable_ && !imported && !ctx->primary_pool()) ctx->set_primary_pool(pool); // the engine's own pool: the reserve is its
   const bool cold = pool->creations() == 0;
   const bool fill = options().zero_fill.load() && !imported;
   const size_t kMaxRunBytes = ps * (size_t)std::max<int64_t>(1, options().access_run_slots.load());
@@ -1161,7 +1202,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
   auto flush_for_batch = [&]() {
     const int64_t t_rw = now_ns();
     if (prt_dirty) { // rewritten before the invalidation that covers them (DrmVm::refresh_prt_remainders)
-      if (!env_bool("KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH", false) && !DrmVm::instance().refresh_prt_remainders()) // (hook: prove the test has teeth)
+      if (!KVC_TEST_HOOK("SKIP_PRT_REMAINDER_REFRESH") && !DrmVm::instance().refresh_prt_remainders()) // (hook: prove the test has teeth)
         throw GpuError("rewriting the remainders of split PRT mappings failed");
       tlb_stale().store(true);
       need_epoch = ctx->next_flush_epoch();
@@ -1436,14 +1477,22 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     throw;
   }
   stats().pages_mapped += (int64_t)(done.size() + kept.size());
-  // Cold start: the first extents this pool ever had to create bring the reserve along, sized like themselves
-  // (KVCACHED_PHYS_RESERVE_MB): pages that come back are zeroed behind the unmap, and a free()+alloc()
-  // cycle that can draw on an idle batch never waits for that fill. One-off, here rather than on the watcher's next
-  // ticks so that it does not depend on a thread being around (a bare C-ABI caller has none); the watcher keeps it up.
-  if (cold && pool->creations() > 0 && !imported && !exportable_) { // (the reserve belongs to the engine's own pool, not to the exportable twin)
-    const size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / ps;
-    if (want) (void)pool->refill_reserve(want, want);
-  }
+  if (cold && pool->creations() > 0 && !imported && !exportable_) cold_start_reserve(pool); // (the reserve belongs to the engine's own pool, not to the exportable twin)
+}
+
+// Cold start: the first extents a pool ever had to create bring the reserve along, sized like themselves
+// (KVCACHED_PHYS_RESERVE_MB): pages that come back are zeroed behind the unmap, and a free()+alloc() cycle
+// that can draw on an idle batch never waits for that fill. Where a housekeeping thread exists (an engine: PageAllocator's
+// watcher tops the reserve up, 256 pages per 100 ms tick) the caller only pays for as much as one tick would have made -
+// the whole reserve on the first map call was 7.6 ms in the smoke run and ~80 ms on VRAM the kernel has not wiped; a bare
+// C-ABI caller has no such thread and gets it all at once.
+void KvAllocator::cold_start_reserve(ExtentPool *pool) {
+  const size_t unit = pool->page_bytes();
+  size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / unit;
+  if (!want) return;
+  size_t now = want;
+  if (ctx_->has_housekeeper()) now = std::min(want, std::max<size_t>(1, (512u << 20) / unit));
+  (void)pool->refill_reserve(want, now);
 }
 
 void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
@@ -1579,7 +1628,7 @@ void KvAllocator::unmap_collect(const std::vector<Slot> &slots, Unmapped &u) {
   }
   flush_run();
   sg.mark(13);
-  if (!touched.items().empty() && !env_bool("KVCACHED_TEST_SKIP_REMAINDER_REFRESH", false)) { // hook: prove the test has teeth
+  if (!touched.items().empty() && !KVC_TEST_HOOK("SKIP_REMAINDER_REFRESH")) { // hook: prove the test has teeth
     for (auto &kv : touched.items()) {
       // pieces still handed out beyond the ones this batch takes back = pages of the extent that stay mapped
       if (xpool->pieces_out(kv.first) > kv.second)
@@ -1646,6 +1695,327 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   stats().pages_unmapped += u.n;
 }
 
+// ------------------------------------------------------------------ lanes
+// The geometry engines use on ROCm (the reference forces it there: kvcached/utils.py:150-171) is one region per layer with a
+// K half and a V half, so ONE page id is `rows` = layers x 2 single slots in as many places of the address space
+// (csrc/allocator.cpp:189-206: 64 for Llama-3-8B) and k consecutive page ids are `rows` runs of k slots. What the kernel
+// charges for is the page-table RANGE, not the byte (tools/engine_ioctl_probe.cpp: 2.5 us per MAP, 4.1 per REPLACE over
+// PRT, +0.23 us per further page of the range, 2.7 us per remainder of a PRT mapping that a REPLACE split), so a page id
+// costs `rows` ioctls whatever user space does - and everything else should cost nothing. A page id is allocated and freed as a
+// unit (PageAllocator), so it is BACKED as a unit: a LANE, the `rows` pages behind one page id, taken from and given back
+// to the pool in one piece (1 pool operation per page id instead of 64; what is recycled has exactly the shape that is
+// asked for, so the footprint is that of the page ids in use). A buffer holds k lanes ROW-MAJOR - page (row, lane) at
+// (row x k + lane) - so that k consecutive page ids backed by one call are still ONE ioctl per row; lanes of such a buffer
+// go back one by one (a free lane of a partly used buffer serves the next single page id at full speed: 64 ioctls
+// either way) and the buffer leaves for the driver when the last one is home. ExtentPool does the bookkeeping with the
+// lane as its unit; this file knows where a lane's pages are.
+void KvAllocator::setup_lanes() {
+  lanes_ = false;
+  rows_.clear();
+  lane_pool_ = nullptr;
+  if (!dev_.is_gpu || contiguous_ || exportable_ || layers_.empty() || !ctx_) return;
+  if (!env_bool("KVCACHED_LANE_EXTENTS", true) || options().phys_chunk_pages.load() <= 1) return;
+  if (options().async_unmap.load()) return; // queued unmaps work slot by slot (the reclaimer's chunks): the per-slot path keeps them
+  const bool kv = !unified_pool_ && num_kv_buffers_ == 2;
+  for (auto &r : layers_) {
+    if (r->backfilled && !r->rest_direct()) return; // (zero aliases through ROCr: the fallback's fallback keeps the per-slot path)
+    rows_.push_back(Row{r.get(), 0});
+    if (kv) rows_.push_back(Row{r.get(), r->num_slots() / 2}); // get_v_base_offset, allocator.cpp:46-52
+  }
+  ids_per_row_ = kv ? layers_[0]->num_slots() / 2 : layers_[0]->num_slots();
+  if (rows_.size() >= 2) lane_pool_ = ctx_->lane_extents(rows_.size(), layers_[0]->page_size);
+  if (!lane_pool_) {
+    rows_.clear();
+    return;
+  }
+  lanes_ = true;
+}
+
+namespace {
+// slots [first, first + n) of a region, cut where its rest state must be (zero extent: its pages repeat; PRT: groups)
+template <class F> void for_rest_pieces(const KvRegion &r, size_t first, size_t n, F &&f) {
+  const size_t g = r.rest_group();
+  while (n) {
+    const size_t take = g == (size_t)-1 ? n : std::min(n, g - first % g);
+    f(first, take);
+    first += take;
+    n -= take;
+  }
+}
+} // namespace
+
+bool KvAllocator::try_map_lanes(const offset_t *offsets, size_t n) {
+  if (!n) return true;
+  const size_t R = rows_.size(), ps = rows_[0].r->page_size;
+  SegTimer sg;
+  // Every slot the call names must be unbacked. Anything else - a page id named twice, a slot that is mapped already, an
+  // imported page, a queued unmap, an offset that is none - is the generic path's business (it logs and goes on, or
+  // throws, as the reference does: ftensor.cpp:104-107).
+  uint64_t need_epoch = 0;
+  RunScan scan;
+  for (size_t i = 0; i < n; ++i) {
+    const offset_t off = offsets[i];
+    if (off < 0 || (size_t)off % ps != 0 || (size_t)off / ps >= ids_per_row_) return false;
+    const size_t p = (size_t)off / ps;
+    for (const Row &row : rows_) {
+      if (row.r->mapped[row.first + p] != 0) return false;
+      need_epoch = std::max(need_epoch, row.r->stale_epoch[row.first + p]);
+    }
+    if (!scan.add(rows_[0].r, rows_[0].first + p)) return false;
+  }
+  GpuContext *ctx = ctx_;
+  ctx->bind();
+  ExtentPool *pool = lane_pool_;
+  if (!ctx->primary_pool()) ctx->set_primary_pool(pool);
+  const bool cold = pool->creations() == 0;
+  const bool fill = options().zero_fill.load() != 0;
+  if (vmm_hip_registered()) // once per slot (a rest_direct region did it when it was made)
+    for (size_t i = 0; i < n; ++i)
+      for (const Row &row : rows_)
+        if (!row.r->registered[row.first + (size_t)offsets[i] / ps]) {
+          const int64_t t0 = now_ns();
+          register_slot(*row.r, row.first + (size_t)offsets[i] / ps);
+          stats().t_unmap_alias += now_ns() - t0;
+        }
+  sg.mark(1);
+  const std::vector<SlotRun> runs = scan.collect();
+  stats().seg[23] += (int64_t)runs.size();
+  sg.mark(2);
+
+  struct Chunk {
+    size_t p, k, rows_done;
+    bool settled; // the slots name the lanes
+    Phys lane[kMaxExtentPages];
+  };
+  std::vector<Chunk> done;
+  std::vector<void *> pending;
+  uint64_t max_ticket = 0;
+  size_t prescrubbed = 0, ids = 0;
+  bool prt_dirty = false, replaced = false, launched = false;
+  void *zx_dirty = nullptr;
+  DrmVm &vm = DrmVm::instance();
+  try {
+    for (const SlotRun &run : runs) {
+      for (size_t at = run.first - rows_[0].first, end = at + run.count; at < end;) {
+        done.emplace_back();
+        Chunk &c = done.back();
+        c.p = at;
+        c.k = c.rows_done = 0;
+        c.settled = false;
+        bool recycled = false;
+        const int64_t t1 = now_ns();
+        c.k = pool->acquire_run(end - at, c.lane, &recycled, false);
+        if (!c.k) c.k = pool->acquire_run(end - at, c.lane, &recycled, true);
+        const int64_t t2 = now_ns();
+        sg.mark(3);
+        unsigned j0 = 0, ke = 1;
+        void *bo = vmm_direct_bo(c.lane[0].h, &j0, &ke);
+        if (!bo) throw GpuError("a lane's buffer is not a direct DRM buffer");
+        for (size_t r = 0; r < R; ++r) { // one ioctl per row: pages (r, j0 .. j0 + k) are neighbours in the buffer
+          KvRegion &reg = *rows_[r].r;
+          char *va = reg.base + (rows_[r].first + at) * ps;
+          const uint64_t boff = ((uint64_t)r * ke + j0) * ps;
+          int rc;
+          if (reg.rest_direct()) { // pages take the place of the rest mapping in the same ioctl
+            tlb_stale().store(true);
+            rc = vm.replace(bo, va, c.k * ps, boff);
+            tlb_stale().store(true); // what was there may sit in a TLB (a zero alias; a PRT entry that was looked at: §4.2)
+            replaced = true;
+            if (reg.zx) zx_dirty = vm.find(reg.zx_handle);
+            if (reg.prt) prt_dirty = true;
+          } else {
+            rc = vm.map(bo, va, c.k * ps, boff);
+          }
+          if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA (backing a page id) failed: ") + strerror(rc < 0 ? -rc : rc));
+          c.rows_done = r + 1;
+        }
+        stats().seg[21] += (int64_t)R;
+        stats().t_acquire += t2 - t1;
+        stats().t_map += now_ns() - t2;
+        sg.mark(4);
+        for (size_t j = 0; j < c.k; ++j) {
+          max_ticket = std::max(max_ticket, c.lane[j].wait_ticket);
+          const bool clean = fill && c.lane[j].scrub_ticket != 0;
+          if (clean) {
+            max_ticket = std::max(max_ticket, c.lane[j].scrub_ticket);
+            prescrubbed += R;
+          }
+          for (size_t r = 0; r < R; ++r) {
+            KvRegion &reg = *rows_[r].r;
+            const size_t idx = rows_[r].first + at + j;
+            reg.handle[idx] = c.lane[j].h;
+            reg.seq[idx] = c.lane[j].seq;
+            reg.mapped[idx] = 4;
+            if (fill && !clean) pending.push_back(reg.base + idx * ps);
+          }
+        }
+        c.settled = true;
+        ids += c.k;
+        at += c.k;
+        sg.mark(5);
+      }
+    }
+    // nothing may reach the new pages through a stale translation of their own addresses: the remainders of what the
+    // REPLACEs split are rewritten (their page-table entries still carry the fragment of the whole), then the invalidation
+    const int64_t t_rw = now_ns();
+    if (prt_dirty && !KVC_TEST_HOOK("SKIP_PRT_REMAINDER_REFRESH") && !vm.refresh_prt_remainders())
+      throw GpuError("rewriting the remainders of split PRT mappings failed");
+    if (zx_dirty && !vm.refresh_mappings_of(zx_dirty, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of the zero extent failed");
+    stats().seg[20] += now_ns() - t_rw;
+    if (replaced) {
+      tlb_stale().store(true);
+      need_epoch = ctx->next_flush_epoch();
+    }
+    if (options().map_waits_for_all_flushes.load() || options().map_shootdown_always.load()) {
+      if (options().map_shootdown_always.load()) tlb_stale().store(true);
+      ctx->ensure_flushed();
+    } else {
+      ctx->ensure_flushed_through(need_epoch);
+    }
+    sg.mark(6);
+    const int64_t ts = now_ns();
+    for (size_t i = 0; i < pending.size(); i += kMaxPtrsPerLaunch) { // fresh memory, or pages that came back unscrubbed
+      ctx->zero_fill(pending.data() + i, std::min<size_t>(kMaxPtrsPerLaunch, pending.size() - i), ps, nullptr);
+      launched = true;
+    }
+    if (launched) ctx->sync(nullptr);
+    sg.mark(7);
+    ctx->wait_scrub(max_ticket);
+    stats().t_sync += now_ns() - ts;
+    sg.mark(8);
+  } catch (...) {
+    if (launched) (void)hipStreamSynchronize(ctx->stream());
+    for (auto it = done.rbegin(); it != done.rend(); ++it) {
+      for (size_t r = 0; r < it->rows_done; ++r) {
+        KvRegion &reg = *rows_[r].r;
+        if (reg.rest_direct())
+          for_rest_pieces(reg, rows_[r].first + it->p, it->k, [&](size_t first, size_t cnt) { (void)rest_replace(reg, first, cnt); });
+        else
+          (void)vmm_try_unmap(reg.base + (rows_[r].first + it->p) * ps, it->k * ps, it->lane[0].h);
+      }
+      if (it->settled)
+        for (size_t j = 0; j < it->k; ++j)
+          for (const Row &row : rows_) row.r->mapped[row.first + it->p + j] = 0;
+      if (it->k) pool->release_batch(it->lane, it->k);
+    }
+    (void)hipGetLastError();
+    try {
+      ctx->tlb_shootdown();
+    } catch (...) {
+    }
+    throw;
+  }
+  stats().pages_mapped += (int64_t)(ids * R);
+  if (prescrubbed) stats().pages_prescrubbed += (int64_t)prescrubbed;
+  if (cold && pool->creations() > 0) cold_start_reserve(pool);
+  return true;
+}
+
+size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<offset_t> *others) {
+  const size_t R = rows_.size(), ps = rows_[0].r->page_size;
+  SegTimer sg;
+  RunScan scan;
+  for (size_t i = 0; i < n; ++i) {
+    const offset_t off = offsets[i];
+    const bool valid = off >= 0 && (size_t)off % ps == 0 && (size_t)off / ps < ids_per_row_;
+    if (valid && rows_[0].r->mapped[rows_[0].first + (size_t)off / ps] == 4) {
+      if (!scan.add(rows_[0].r, rows_[0].first + (size_t)off / ps)) KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", (size_t)off / ps); // named twice
+    } else {
+      others->push_back(off);
+    }
+  }
+  if (!scan.size()) return 0;
+  GpuContext *ctx = ctx_;
+  ctx->bind();
+  ExtentPool *pool = lane_pool_;
+  const std::vector<SlotRun> runs = scan.collect();
+  sg.mark(11);
+  std::vector<Phys> lanes;
+  KeyGroups<uint32_t> touched(n); // buffer -> lanes of it that this call takes back
+  bool any_backfilled = false;
+  for (const SlotRun &run : runs) {
+    const size_t p0 = run.first - rows_[0].first;
+    for (size_t r = 0; r < R; ++r) {
+      KvRegion &reg = *rows_[r].r;
+      const int64_t t0 = now_ns();
+      if (reg.rest_direct()) { // back to the rest state, whatever is mapped there, in one ioctl per piece
+        for_rest_pieces(reg, rows_[r].first + p0, run.count, [&](size_t first, size_t cnt) {
+          const int rc = rest_replace(reg, first, cnt);
+          if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA replace (back to the rest state) failed: ") + strerror(rc < 0 ? -rc : rc));
+          stats().seg[22]++;
+        });
+        any_backfilled = any_backfilled || reg.backfilled;
+      } else {
+        vmm_unmap_run(reg.base + (rows_[r].first + p0) * ps, run.count * ps);
+        stats().seg[22]++;
+      }
+      stats().t_unmap += now_ns() - t0;
+    }
+    for (size_t p = p0; p < p0 + run.count; ++p) {
+      const size_t idx0 = rows_[0].first + p;
+      const phys_handle_t h = rows_[0].r->handle[idx0];
+      lanes.push_back(Phys{h, rows_[0].r->seq[idx0]});
+      ++touched.at(chunk_of(h));
+    }
+  }
+  sg.mark(12);
+  for (const SlotRun &run : runs)
+    for (const Row &row : rows_) {
+      const size_t first = row.first + (run.first - rows_[0].first);
+      std::fill(row.r->mapped.begin() + first, row.r->mapped.begin() + first + run.count, 0);
+    }
+  sg.mark(13);
+  // Lanes that were backed together share one mapping per row; taking some of them out splits it, and what is left of it
+  // must be written again before the invalidation (DrmVm::refresh_mappings_of, §4.8). A buffer that loses ALL its mapped
+  // lanes here leaves nothing behind.
+  if (!KVC_TEST_HOOK("SKIP_REMAINDER_REFRESH")) {
+    bool any = false;
+    for (auto &kv : touched.items())
+      if (pool->pieces_out(kv.first) > kv.second)
+        if (void *bo = DrmVm::instance().find(kv.first)) {
+          if (!DrmVm::instance().refresh_mappings_of(bo, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of a buffer failed");
+          any = true;
+        }
+    if (any) tlb_stale().store(true);
+  }
+  sg.mark(14);
+  const uint64_t epoch = ctx->next_flush_epoch(); // every driver call that removed or rewrote a translation has returned
+  for (const SlotRun &run : runs)
+    for (const Row &row : rows_) {
+      const size_t first = row.first + (run.first - rows_[0].first);
+      std::fill(row.r->stale_epoch.begin() + first, row.r->stale_epoch.begin() + first + run.count, epoch);
+    }
+  sg.mark(15);
+  // the invalidation: inside the call where unbacked VA promises zeros (compat), behind it otherwise (see unmap_finish)
+  const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
+  if (any_backfilled || !defer)
+    ctx->ensure_flushed();
+  else if (options().defer_unmap_shootdown.load())
+    ctx->defer_tlb_shootdown();
+  else
+    ctx->request_async_flush();
+  sg.mark(16);
+  const int64_t tr0 = now_ns();
+  // zeroed on their way back, through the alias mapping of their buffer: page (row, lane) sits at (row x k + lane)
+  uint64_t ticket = 0;
+  if (options().zero_fill.load() && options().scrub_on_release.load()) {
+    std::vector<uint64_t> addrs;
+    addrs.reserve(lanes.size() * R);
+    for (const Phys &l : lanes)
+      if (const uint64_t tag = pool->tag_of(l.h)) {
+        const uint64_t ke = pages_of(l.h), j = piece_of(l.h);
+        for (size_t r = 0; r < R; ++r) addrs.push_back(tag + ((uint64_t)r * ke + j) * ps);
+      }
+    if (!addrs.empty()) ticket = ctx->scrub(addrs.data(), addrs.size(), ps);
+  }
+  sg.mark(17);
+  pool->release_batch(lanes.data(), lanes.size(), ticket);
+  sg.mark(18);
+  stats().t_release += now_ns() - tr0;
+  stats().pages_unmapped += (int64_t)(lanes.size() * R);
+  return lanes.size();
+}
+
 // ------------------------------------------------------------------ TP shared pool
 // hipMemImportFromShareableHandle's `osHandle` convention differs between HIP runtimes: the one
 // bundled with PyTorch 2.10+rocm7.0 dereferences it as `int *` (passing the fd by value
@@ -1662,7 +2032,7 @@ static phys_handle_t import_posix_fd(int fd) {
     // pages seen from a peer over xGMI) may be refused by this shortcut - ROCr's import, which sets up peer access for
     // the local agent, is the fallback (hsa_amd_vmem_import_shareable_handle + map + set_access below).
     try {
-      if (env_bool("KVCACHED_TEST_FAIL_KFD_IMPORT", false)) throw GpuError("AMDKFD_IOC_IMPORT_DMABUF failed [injected]");
+      if (KVC_TEST_HOOK("FAIL_KFD_IMPORT")) throw GpuError("AMDKFD_IOC_IMPORT_DMABUF failed [injected]");
       return DrmVm::instance().import_fd(fd);
     } catch (const GpuError &e) {
       static std::atomic<bool> warned{false};

@@ -90,6 +90,15 @@ public:
   // What map/unmap take pages from (extent_pool.hpp): run-sized extents of up to KVCACHED_PHYS_CHUNK_PAGES pages with
   // the drm backend and pages straight from KFD (non-exportable pools), single pages everywhere else.
   ExtentPool *extents(size_t page_bytes, bool exportable);
+  // The pool of an allocator whose page ids are `rows` slots in `rows` places of the address space (one per layer and K/V
+  // half: the non-contiguous layout engines use on ROCm): its unit is a LANE - the `rows` pages behind one page id - and an
+  // extent is one buffer of up to KVCACHED_LANE_EXTENT_MB holding k lanes row-major (page (row, lane) at (row * k + lane)),
+  // so that k consecutive page ids are ONE map ioctl per row and a page id is acquired, scrubbed and released as a unit
+  // (DESIGN.md §4.11). drm backend with pages straight from KFD only (nullptr otherwise).
+  ExtentPool *lane_extents(size_t rows, size_t page_bytes);
+  // the pool the engine's own pages come from (the reserve and the footprint diagnostics belong to it)
+  void set_primary_pool(ExtentPool *p) { primary_pool_.store(p); }
+  ExtentPool *primary_pool() const { return primary_pool_.load(); }
   void drain_pools();
   size_t idle_pool_bytes(); // physical memory parked in the handle pools: ours to reuse, invisible to hipMemGetInfo
   // 10 Hz from the allocator's watcher thread: drain idle handles if the device is short of free memory, and
@@ -194,6 +203,9 @@ private:
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
+  std::map<std::pair<size_t, size_t>, std::unique_ptr<ExtentPool>> lane_pools_; // key: (rows, page bytes)
+  std::atomic<ExtentPool *> primary_pool_{nullptr};
+  ExtentDriver make_driver(size_t unit_bytes, bool exportable, bool aliases);
   std::vector<ExtentPool *> all_pools();
   KfdTlbFlush kfd_flush_;
   void *fallback_block_ = nullptr; // the 2 MiB allocation whose hipFree is the next invalidation of the hipMalloc/hipFree fallback
@@ -270,7 +282,8 @@ struct KvRegion {
   bool in_full_group(size_t slot) const { return reg_group > 1 && slot / reg_group < num_slots() / reg_group; }
   std::vector<uint64_t> mark;          // one bit per slot, all clear at rest: scratch of RunScan (kv_allocator.cpp), under the allocator's lock
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
-                                       // 3 = released by the caller, physical unmap still queued (async unmap)
+                                       // 3 = released by the caller, physical unmap still queued (async unmap),
+                                       // 4 = backed by a page of a LANE (handle = the lane's: one per page id, shared by all its rows)
   size_t num_slots() const { return size / page_size; }
 };
 
@@ -299,6 +312,7 @@ public:
   bool unmap_from_kv_tensors(const offset_t *offsets, size_t n);
   std::vector<void *> region_bases(); // layer-major, K then V (compact_blocks' region table)
   bool uses_prt();                    // unbacked slots of this group's regions are PRT mappings
+  size_t lanes_per_extent();          // page ids are backed by lanes: lanes a buffer holds at most (0: per-slot pages)
 
   // async unmap (KVC_OPT_ASYNC_UNMAP): wait until every queued unmap of this allocator / of all allocators has
   // been carried out; bytes still queued (they count as free for this process)
@@ -341,6 +355,15 @@ private:
   void unmap_collect(const std::vector<Slot> &slots, Unmapped &out);
   void unmap_finish(Unmapped &u, bool may_defer_shootdown);
   void reclaimer_loop();
+  // ---- lanes (kv_allocator.cpp, "lanes"): page ids of a multi-row geometry backed, scrubbed and released as units
+  struct Row {
+    KvRegion *r;
+    size_t first; // slot of page id p in this row = first + p
+  };
+  void setup_lanes();                                      // after the regions exist: decide, build the row table
+  bool try_map_lanes(const offset_t *offsets, size_t n);   // false: nothing done, the generic path takes the call
+  size_t unmap_lanes(const offset_t *offsets, size_t n, std::vector<offset_t> *others); // lanes unmapped; offsets that are not lane-backed -> others
+  void cold_start_reserve(ExtentPool *pool);
   bool steal_pending(size_t page_size, Phys *out);
   void lock_foreground(std::unique_lock<std::mutex> &lk); // mu_ with priority over the reclaimer
 
@@ -354,6 +377,10 @@ private:
   size_t tensor_bytes_per_layer_ = 0;
   std::mutex mu_;
   std::vector<std::unique_ptr<KvRegion>> layers_; // per-layer regions, or ONE region in contiguous layout
+  bool lanes_ = false;           // page ids are backed by lanes
+  std::vector<Row> rows_;        // layer-major, K then V: the order slots_for() lists the slots of one offset in
+  size_t ids_per_row_ = 0;       // page ids a row has room for
+  ExtentPool *lane_pool_ = nullptr;
   // async unmap state (guarded by mu_)
   std::deque<Slot> pending_;
   std::condition_variable pending_cv_, drained_cv_;

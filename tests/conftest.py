@@ -20,8 +20,25 @@ os.environ.setdefault("KVCACHED_CONTIGUOUS_LAYOUT", "false")
 import pytest  # noqa: E402
 
 
+HOOKS_DIR = os.path.join(REPO, "kvcached_amd", "_testhooks")
+
+
+def hooks_env(base=None):
+    """Environment of a child process that loads the library build with the test hooks compiled in
+    (kvcached_amd/_testhooks/libkvcached_amd.so, -DKVC_TEST_HOOKS: the KVCACHED_TEST_* switches remove a safety step so that a
+    test can show it would notice). The shipped library has neither the code nor the names; nothing but such children ever
+    loads the hooks build."""
+    env = dict(os.environ if base is None else base)
+    env["KVCACHED_AMD_LIBRARY"] = os.path.join(HOOKS_DIR, "libkvcached_amd.so")
+    env["LD_LIBRARY_PATH"] = HOOKS_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")   # vmm_ops' DT_NEEDED resolves to the same file
+    env["KVC_HOOKS_CHILD"] = "1"
+    return env
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "hooks_build: the test body needs KVCACHED_TEST_* hooks: it runs in a child pytest that loads "
+                                       "the library build with the hooks compiled in (the parent session keeps the shipped library)")
     # checkers and product are built once per session; both are no-ops when up to date
     if not os.path.exists(os.path.join(REPO, "oracle", "libkvc_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "oracle"])
@@ -35,6 +52,21 @@ def pytest_configure(config):
         stale = True
     if stale:
         kb.build_all()
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """A test marked `hooks_build` is executed by a child pytest session that loads the hooks build; this session only checks
+    the child's verdict (and never sees a hook itself)."""
+    if pyfuncitem.get_closest_marker("hooks_build") is None or os.environ.get("KVC_HOOKS_CHILD") == "1":
+        return None
+    env = hooks_env()
+    env["KVCACHED_IPC_NAME"] = f"kvc_test_hooks_{os.getpid()}"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "gpu or not gpu", pyfuncitem.nodeid],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "in the hooks build:\n" + r.stdout[-3000:] + r.stderr[-1500:]
+    assert "1 passed" in r.stdout, r.stdout[-800:]
+    return True
 
 
 def pytest_collection_modifyitems(config, items):

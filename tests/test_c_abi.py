@@ -136,3 +136,23 @@ def test_page_allocator_surface_and_errors():
         del pa
     finally:
         vmm_ops.shutdown_kvcached()
+
+
+def test_the_shipped_library_has_no_test_hooks():
+    """The switches that remove a safety step for the benefit of a test (KVCACHED_TEST_*: skip the TLB invalidation, the
+    rewrite of split mappings, fail a self test) are compiled into a second build that only the tests' own child processes load
+    (kvcached_amd/_testhooks/, build.py); the library that ships has neither the code nor the names, so no environment can
+    switch page privacy off in a deployment."""
+    from kvcached_amd import capi
+    here = os.path.join(T.REPO, "kvcached_amd")
+    with open(os.path.join(here, "libkvcached_amd.so"), "rb") as f:
+        shipped = f.read()
+    assert re.search(rb"KVCACHED_TEST_[A-Z_]+", shipped) is None
+    with open(os.path.join(here, "_testhooks", "libkvcached_amd.so"), "rb") as f:
+        hooked = f.read()
+    names = {m.decode() for m in re.findall(rb"KVCACHED_TEST_[A-Z_]+", hooked)}
+    assert {"KVCACHED_TEST_BREAK_TLB_FLUSH", "KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH", "KVCACHED_TEST_FAIL_DRM_SELFTEST"} <= names, names
+    # and the hooks build is the same library otherwise: same ABI
+    lib = ctypes.CDLL(os.path.join(here, "_testhooks", "libkvcached_amd.so"))
+    lib.kvc_abi_version.restype = ctypes.c_int
+    assert lib.kvc_abi_version() == capi.lib.kvc_abi_version()

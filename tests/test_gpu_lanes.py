@@ -1,0 +1,207 @@
+"""Page ids of the geometry engines use on ROCm - one region per layer, K half and V half (the reference forces the
+non-contiguous layout there: kvcached/utils.py:150-171, csrc/allocator.cpp:189-206) - are backed as units: a LANE is the
+`rows` pages behind one page id, one buffer holds k lanes row-major, k consecutive page ids are one ioctl per row
+(DESIGN.md §4.11). What must hold is what held slot by slot: every page of every page id reads zero when it is handed
+out, keeps what was written to it and nothing else, goes back as a whole, and the ledger balances."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MiB = 1 << 20
+PAGE = 2 * MiB
+DEV = "cuda:0"
+EPP = PAGE // 2   # int16 elements per page
+
+
+@pytest.fixture()
+def lanes():
+    from kvcached_amd import capi, vmm_ops
+    saved = {k: os.environ.get(k) for k in ("KVCACHED_PHYS_RESERVE_MB", "KVCACHED_ZERO_BACKFILL", "KVCACHED_LANE_EXTENT_MB")}
+    os.environ["KVCACHED_PHYS_RESERVE_MB"] = "0"
+    yield {"ops": vmm_ops, "capi": capi}
+    vmm_ops.shutdown_kvcached()
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    capi.set_option(capi.OPT_ZERO_BACKFILL, 1)
+
+
+def _engine(state, layers, ids_per_half, compat, lane_mb=None):
+    ops, capi = state["ops"], state["capi"]
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if compat else "false"
+    if lane_mb is not None:
+        os.environ["KVCACHED_LANE_EXTENT_MB"] = str(lane_mb)
+    ops.init_kvcached(DEV, PAGE, False)
+    ts = ops.create_kv_tensors(2 * ids_per_half * PAGE, 2, DEV, layers, 2, 0, False)
+    views = []
+    for t in ts:                                   # row order = the order map_to_kv_tensors walks: layer-major, K then V
+        views.append(t[:ids_per_half * EPP].view(ids_per_half, EPP))
+        views.append(t[ids_per_half * EPP:].view(ids_per_half, EPP))
+    return ops, capi, views
+
+
+def _stamp(views, ids, base):
+    for r, v in enumerate(views):
+        for p in ids:
+            v[p].fill_(base + 16 * r + (p % 16))
+    torch.cuda.synchronize()
+
+
+def _check(views, ids, base):
+    for r, v in enumerate(views):
+        for p in ids:
+            want = base + 16 * r + (p % 16)
+            assert bool((v[p][::4096] == want).all()), (r, p)
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_page_ids_are_backed_and_given_back_as_units(lanes, compat):
+    ops, capi, views = _engine(lanes, layers=4, ids_per_half=64, compat=compat)
+    R = len(views)
+    assert R == 8 and capi.get_option(129) >= 8          # lanes in use, up to 8 (1 GiB / (8 rows x 2 MiB) caps at 64 -> 64; at least 8)
+    capi.reset_stats()                                   # once: the ledger at the end counts from here
+    snap = lambda: (capi.get_stats()["pages_mapped"], capi.get_option(130 + 21), capi.get_option(130 + 23))   # noqa: E731  pages, ioctls, runs
+    delta = lambda a, b: tuple(y - x for x, y in zip(a, b))                                                     # noqa: E731
+    # one page id: R slots, R ioctls, one lane
+    s0 = snap()
+    assert ops.map_to_kv_tensors([5 * PAGE])
+    assert delta(s0, snap()) == (R, R, 1)
+    for v in views:
+        assert int(torch.count_nonzero(v[5])) == 0
+    # eight consecutive page ids in one call: still R ioctls (one run per row), one buffer
+    s0 = snap()
+    ids = list(range(16, 24))
+    assert ops.map_to_kv_tensors([p * PAGE for p in ids])
+    assert delta(s0, snap()) == (8 * R, R, 1)
+    for v in views:
+        assert int(torch.count_nonzero(v[16:24])) == 0
+    _stamp(views, [5] + ids, 1000)
+    _check(views, [5] + ids, 1000)
+    # a page id out of the middle of the run goes back alone: its slots are unbacked again (zeros in compat mode), its
+    # neighbours - pages of the SAME buffer, mapped by the same ioctl - keep every word
+    assert ops.unmap_from_kv_tensors([19 * PAGE])
+    if compat:
+        for v in views:
+            assert int(torch.count_nonzero(v[19][::64])) == 0
+    _check(views, [5, 16, 17, 18, 20, 21, 22, 23], 1000)
+    # ... and the lane that came back serves the next single page id (a free lane of a partly used buffer goes first):
+    # nothing is created, the pages read zero, nothing of the old contents shines through
+    created = capi.get_stats()["handles_created"]
+    assert ops.map_to_kv_tensors([40 * PAGE])
+    assert capi.get_stats()["handles_created"] == created
+    for v in views:
+        assert int(torch.count_nonzero(v[40])) == 0
+    _stamp(views, [40], 3000)
+    _check(views, [5, 16, 17, 18, 20, 21, 22, 23], 1000)
+    _check(views, [40], 3000)
+    # scattered page ids, named in any order, some of them neighbours: runs are found whatever the order
+    s0 = snap()
+    more = [50, 2, 51, 30, 1, 52]
+    assert ops.map_to_kv_tensors([p * PAGE for p in more])
+    assert delta(s0, snap())[0] == len(more) * R and delta(s0, snap())[2] == 3     # {1,2} {30} {50,51,52}
+    _stamp(views, more, 5000)
+    _check(views, more, 5000)
+    _check(views, [40], 3000)
+    everything = [5, 16, 17, 18, 20, 21, 22, 23, 40] + more
+    u0 = capi.get_stats()["pages_unmapped"]
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in everything])
+    assert capi.get_stats()["pages_unmapped"] - u0 == len(everything) * R
+    if compat:
+        for v in views:
+            assert int(torch.count_nonzero(v[:, ::4096])) == 0
+    # recycled lanes come back clean
+    assert ops.map_to_kv_tensors([p * PAGE for p in (7, 8, 9)])
+    for v in views:
+        assert int(torch.count_nonzero(v[7:10])) == 0
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in (7, 8, 9)])
+    assert capi.get_option(124) == 0                     # no release the pool did not know
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"] and st["handles_created"] % R == 0
+
+
+def test_every_byte_is_zeroed_once_per_use_and_the_fill_has_left_the_map_call(lanes):
+    """§4.9 holds lane by lane: pages are zeroed on their way back (through the alias mapping of their buffer, page (row, lane)
+    at row x k + lane), so a map call that gets recycled lanes launches nothing and still hands out zeros."""
+    ops, capi, views = _engine(lanes, layers=3, ids_per_half=32, compat=True)
+    R = len(views)
+    capi.reset_stats()
+    ids = [3, 4, 5, 6, 20]
+    assert ops.map_to_kv_tensors([p * PAGE for p in ids])            # fresh memory: filled by the map call
+    st = capi.get_stats()
+    assert st["fill_bytes"] == len(ids) * R * PAGE and capi.get_option(capi.OPT_PAGES_PRESCRUBBED) == 0
+    _stamp(views, ids, 700)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in ids])        # scrubbed behind the unmap
+    capi.flush_unmaps()
+    assert capi.get_option(capi.OPT_PAGES_SCRUBBED) == len(ids) * R
+    fills = capi.get_stats()["fill_launches"]
+    assert ops.map_to_kv_tensors([p * PAGE for p in (10, 11, 12, 13, 30)])
+    assert capi.get_stats()["fill_launches"] == fills                # nothing launched by the map call ...
+    assert capi.get_option(capi.OPT_PAGES_PRESCRUBBED) == len(ids) * R
+    for v in views:                                                  # ... and every word is zero
+        assert int(torch.count_nonzero(v[10:14])) == 0 and int(torch.count_nonzero(v[30])) == 0
+    st = capi.get_stats()
+    assert st["fill_bytes"] == (st["pages_mapped"] - capi.get_option(capi.OPT_PAGES_PRESCRUBBED) + capi.get_option(capi.OPT_PAGES_SCRUBBED)) * PAGE
+
+
+def test_a_call_the_lanes_cannot_take_goes_the_per_slot_way(lanes):
+    """A page id named twice, or one that is backed already: the reference logs and goes on (csrc/ftensor.cpp:104-107). Such a
+    call takes the per-slot path as a whole; pages backed either way live side by side and both kinds go back."""
+    ops, capi, views = _engine(lanes, layers=2, ids_per_half=32, compat=True)
+    R = len(views)
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([4 * PAGE])                         # a lane
+    _stamp(views, [4], 100)
+    m0 = capi.get_stats()["pages_mapped"]
+    assert ops.map_to_kv_tensors([4 * PAGE, 9 * PAGE])               # 4 is backed: logged and skipped; 9 is backed slot by slot
+    assert capi.get_stats()["pages_mapped"] - m0 == R
+    _check(views, [4], 100)
+    for v in views:
+        assert int(torch.count_nonzero(v[9])) == 0
+    _stamp(views, [9], 200)
+    assert ops.map_to_kv_tensors([6 * PAGE, 6 * PAGE])               # named twice
+    _check(views, [9], 200)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in (9, 4, 6)])  # both kinds in one call
+    for v in views:
+        assert int(torch.count_nonzero(v[:, ::4096])) == 0
+    assert ops.unmap_from_kv_tensors([4 * PAGE])                     # not mapped: logged, the call succeeds
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
+def test_a_driver_failure_rolls_a_lane_batch_back(lanes):
+    ops, capi, views = _engine(lanes, layers=2, ids_per_half=32, compat=True, lane_mb=16)    # 16 MiB buffers: 2 lanes each (4 rows x 2 MiB)
+    assert capi.get_option(129) == 2
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([0])
+    _stamp(views, [0], 50)
+    capi.set_option(104, 1)                                          # the second creation from now fails
+    with pytest.raises(RuntimeError):
+        ops.map_to_kv_tensors([p * PAGE for p in range(10, 16)])     # 3 buffers of 2 lanes
+    capi.set_option(104, -1)
+    for v in views:                                                  # nothing of the batch is left behind
+        assert int(torch.count_nonzero(v[10:16, ::4096])) == 0
+    _check(views, [0], 50)
+    assert ops.map_to_kv_tensors([p * PAGE for p in range(10, 16)])  # and the same call works afterwards
+    for v in views:
+        assert int(torch.count_nonzero(v[10:16])) == 0
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in [0] + list(range(10, 16))])
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
+def test_lanes_can_be_switched_off(lanes, monkeypatch):
+    monkeypatch.setenv("KVCACHED_LANE_EXTENTS", "false")
+    ops, capi, views = _engine(lanes, layers=2, ids_per_half=16, compat=True)
+    assert capi.get_option(129) == 0
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([3 * PAGE])
+    assert capi.get_stats()["pages_mapped"] == len(views)
+    assert ops.unmap_from_kv_tensors([3 * PAGE])

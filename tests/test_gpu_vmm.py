@@ -397,7 +397,8 @@ def test_backed_slots_are_not_shadowed_by_their_unbacked_neighbours():
     base.pop("KVCACHED_ZERO_BACKFILL", None)
     ok = subprocess.run([sys.executable, "-c", _NEIGHBOUR_CHILD % repo], env=base, capture_output=True, text=True, timeout=300)
     assert ok.returncode == 0 and "WRONG WORDS 0" in ok.stdout, (ok.stdout[-500:], ok.stderr[-1500:])
-    broken = subprocess.run([sys.executable, "-c", _NEIGHBOUR_CHILD % repo], env=dict(base, KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH="1"),
+    from conftest import hooks_env   # the hook exists only in the tests' own build of the library
+    broken = subprocess.run([sys.executable, "-c", _NEIGHBOUR_CHILD % repo], env=hooks_env(dict(base, KVCACHED_TEST_SKIP_PRT_REMAINDER_REFRESH="1")),
                             capture_output=True, text=True, timeout=300)
     assert broken.returncode == 0, broken.stderr[-1500:]
     wrong = int(broken.stdout.split("WRONG WORDS")[1].split()[0])
@@ -705,7 +706,8 @@ def test_init_refuses_to_start_when_tlb_invalidation_is_ineffective(backend):
     base = dict(os.environ, KVCACHED_VMM_BACKEND=backend, KVCACHED_LOG_LEVEL="ERROR")
     ok = subprocess.run([sys.executable, "-c", _TLB_CHILD % repo], env=base, capture_output=True, text=True, timeout=240)
     assert ok.returncode == 0 and "INIT OK" in ok.stdout, (ok.stdout, ok.stderr[-800:])
-    broken = subprocess.run([sys.executable, "-c", _TLB_CHILD % repo], env=dict(base, KVCACHED_TEST_BREAK_TLB_FLUSH="1"),
+    from conftest import hooks_env   # the hook exists only in the tests' own build of the library
+    broken = subprocess.run([sys.executable, "-c", _TLB_CHILD % repo], env=hooks_env(dict(base, KVCACHED_TEST_BREAK_TLB_FLUSH="1")),
                             capture_output=True, text=True, timeout=240)
     assert broken.returncode == 0, broken.stderr[-800:]
     assert "INIT REFUSED" in broken.stdout and "TLB invalidation is ineffective" in broken.stdout, broken.stdout
@@ -837,6 +839,7 @@ def test_async_unmap_queue_reclaimer_and_rebacking(vmm):
     capi.set_option(capi.OPT_ASYNC_UNMAP, 0)
 
 
+@pytest.mark.hooks_build
 def test_default_backend_and_its_fallback_chain(vmm, monkeypatch):
     """Default: drm (own pages mapped with one GEM_VA ioctl) on top of hybrid (slots registered with
     HIP once, everything else through ROCr, §4.6); plain HIP copies keep working on such memory. Each layer is checked
@@ -860,6 +863,7 @@ def test_default_backend_and_its_fallback_chain(vmm, monkeypatch):
         ops.shutdown_kvcached()
 
 
+@pytest.mark.hooks_build
 def test_drm_backend_one_ioctl_per_map_and_its_fallback(vmm, monkeypatch):
     """KVCACHED_VMM_BACKEND=drm: own pages are mapped with one DRM_AMDGPU_GEM_VA ioctl on a buffer
     object imported once per handle. Same observable behaviour as hybrid: zero-filled pages, HIP copies in and out,
@@ -1078,6 +1082,7 @@ def test_export_import_same_process(vmm):
     assert ops.unmap_from_kv_tensors([PAGE], 0)
 
 
+@pytest.mark.hooks_build
 @pytest.mark.parametrize("mode", ["lazy", "compat"])
 def test_import_falls_back_to_rocr_when_the_direct_import_is_refused(vmm, monkeypatch, mode):
     """A peer's page is taken straight into KFD + DRM (AMDKFD_IOC_IMPORT_DMABUF, one GEM_VA map). A buffer that lives on
