@@ -3,9 +3,13 @@
 
 Workload (BASELINE.json configs[1], "bench_vmm: reserve 64 GiB VA, map/unmap 2 MiB pages in 1024-page
 batches"): one STEP = one elastic cycle on one batch of 1024 x 2 MiB pages, sweeping the 64 GiB window:
-  kvc_map_to_kv_tensors(1024 offsets)   pooled/created handles + hipMemMap + hipMemSetAccess + TLB
-                                        shootdown + the zero_fill_pages kernel; returns after the fill
-  kvc_unmap_from_kv_tensors(same)       hipMemUnmap + TLB shootdown + handles back to the pool/driver
+  kvc_map_to_kv_tensors(1024 offsets)   physical pages from the library's pool (run-sized extents) + one page-table ioctl per run
+                                        of adjacent slots + the TLB invalidation the batch owes; the pages were zeroed when
+                                        they came back (zero_fill_pages through their buffers' alias mappings, queued behind the
+                                        previous unmap), so the call only waits for that scrub if it has not finished
+  kvc_unmap_from_kv_tensors(same)       one ioctl per run back to the rest state + TLB invalidation + the zero fill of the
+                                        pages queued on the library's scrub stream + pages back to the pool
+  (the cycle ends with kvc_flush_unmaps inside the timed bracket: every scrub and invalidation in flight is waited for)
 Set-up (untimed, like the VA reservation): every batch of the window is mapped and unmapped once — the warm-up sweep of
 the bench_vmm protocol. It matters: the first ~30 batches a process pushes through the driver are ~20 % slower
 (hipMemMap 3.5 instead of 2.3 us/page) whatever VA they touch; the variant `fresh_va_window_warm_process` shows that
@@ -17,10 +21,15 @@ Both halves are inside the timed bracket; `value` = bytes backed / total wall ti
 variant `growth_burst` (there hipMemCreate's O(live handles) cost dominates).
 
   python bench.py [--gpus N --steps K --warmup W]
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the path shards with no
+N > 1: this script starts its own N ranks (spawn_ranks: one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+torch.distributed.run would; under such a launcher - WORLD_SIZE already set - it is a rank). The path shards with no
 data-path collective — every rank backs its own KV shard — and the only exchange is the one the
 reference has too: rank 0's offset vector is broadcast to the TP group (CollectiveFanout: one RCCL
 broadcast + one status all-reduce per step). Weak scaling: per-GPU work is fixed.
+
+At N = 1 the line also carries the geometry engines really use on ROCm (engine_llama3_8b_noncontig_*: one region per layer,
+K and V halves - one page id = 64 slots in 64 places; benchmarks/bench_engine_geometry.py) and, at N > 1, the shared-pool
+leg (rank 0 backs and exports page ids, the other ranks import and map them and read rank 0's signature through the mapping).
 
 Prints ONE JSON line: metric/value/unit/... + "roofline" (zero_fill_pages, HBM-bound; kernel time
 from HIP events recorded inside the library on the stream the kernel runs on) + "cpu_baseline"
@@ -61,6 +70,9 @@ def parse_args():
     ap.add_argument("--backend", choices=["hip", "hybrid", "drm"], default=os.environ.get("KVCACHED_VMM_BACKEND", "drm"),
                     help="VMM backend requested for the main measurement (library default: drm; DESIGN.md §4.6/§4.7); the line "
                          "reports the one in effect after the library's self tests")
+    ap.add_argument("--shared-pool-leg", action="store_true",
+                    help="internal: this process is one rank of the shared-pool leg (a child of a rank of the N > 1 run, so that a "
+                         "failure in the cross-GPU import cannot take the bench line with it)")
     ap.add_argument("--growth-burst-only", action="store_true",
                     help="internal: run the growth burst (24 x 2 GiB backed, nothing unmapped) as the first GPU work of a "
                          "fresh process and print its summary (the N=1 line's growth_burst_first_touch leg)")
@@ -284,6 +296,40 @@ def compaction_roofline(capi, device):
         capi.shutdown()
 
 
+def engine_geometry(capi, device, mode):
+    """The non-contiguous Llama-3-8B geometry (the reference forces it on ROCm: kvcached/utils.py:150-171; one page id = 32 layers x
+    K/V = 64 slots of 2 MiB in 64 places, csrc/allocator.cpp:189-206) through the same C ABI: 1 / 8 / 64 consecutive page ids
+    per call, pool warm. 'steady': every call finds the address space as its previous visit left it; 'straddling': the runs are
+    shifted against that shape (rest mappings are split, their remainders rewritten); 'scattered': single page ids of a
+    churned free list. Per-call p50, GB/s backed by the map call, and where the host time goes."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_engine_geometry", os.path.join(REPO, "benchmarks", "bench_engine_geometry.py"))
+    eg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eg)
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if mode == "compat" else "false"
+    half = 512                                            # page ids per K (or V) half of a layer: 64 GiB of VA in all
+    capi.init(device, PAGE, False)
+    out = {}
+    try:
+        capi.create_kv_tensors(2 * half * PAGE, 1, device, 32, 2, 0, False)
+        rng = np.random.default_rng(0)
+        for placement, ids in (("steady", (1, 8, 64)), ("straddling", (1, 8)), ("scattered", (8,))):
+            for n in ids:
+                r = eg.run(capi, n, placement, 30, half, 32, rng)
+                name = f"engine_llama3_8b_noncontig_{n}_page_id{'s' if n > 1 else ''}" + ("" if placement == "steady" else f"_{placement}")
+                out[name] = {"p50_map_ms": r["map_ms"]["p50"], "max_map_ms": r["map_ms"]["max"], "p50_unmap_ms": r["unmap_ms"]["p50"],
+                             "map_GBps": r["map_GBps_backed_p50"], "cycle_GBps": r["cycle_GBps"], "us_per_2MiB_map": r["us_per_2MiB_map"],
+                             "slots_2MiB": r["slots_2MiB"], "ioctls_per_map_call": r["per_call"]["map.ioctls_issued"],
+                             "ioctls_per_unmap_call": r["per_call"]["unmap.ioctls_issued"], "tlb_shootdown_us": r["shootdown_us"],
+                             "driver_allocations": r["driver_allocations_in_timed_region"], "host_us_per_call": r["host_us_per_call"]}
+        out["lanes_per_buffer"] = int(capi.get_option(129))
+    finally:
+        capi.shutdown()
+        os.environ.pop("KVCACHED_ZERO_BACKFILL", None)
+    return out
+
+
 def cpu_baseline():
     """The reference's CPU path restated (oracle/, kind "port"), 1 thread, bounded sample: for each
     batch the page-id bookkeeping of the reference allocator (PageAllocator state machine ->
@@ -383,6 +429,150 @@ def reference_on_box(steps, warmup, burst=False):
         return {"error": str(e)[:200]}
 
 
+# ------------------------------------------------------------------ shared pool (BASELINE config 4)
+def shared_pool_leg(rank, world, device, backend, rehearsal):
+    """BASELINE.json configs[3]: "TP=8 shared KV pool: rank-0 create + IPC export, ranks 1-7 map over xGMI" (the reference's own
+    harness only fans offsets out: benchmarks/bench_tp_ipc/kvcached_tp_ipc_benchmark.py:117-212, kvcached/tp_ipc_util.py:173-192).
+    Llama-3-8B geometry on every rank (32 layers x K/V, same VA layout). Per round: rank 0 backs k page ids with exportable
+    pages and writes a signature into each of them; SharedPoolChannel.share(): offsets over the group's collective (RCCL
+    broadcast), one dmabuf fd per 2 MiB slot over SCM_RIGHTS, every other rank imports and maps the SAME physical pages at the same
+    offsets; each of them reads the signature through its own mapping with a kernel on ITS GPU (rank 0's memory: the read
+    crosses xGMI) and the ranks agree on the result; everything is unmapped again. Reports ms per page id and which import path
+    the peers took (straight into KFD + DRM, or the runtime's import - the fallback for a buffer the direct path refuses)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from kvcached_amd import capi, vmm_ops
+    from kvcached_amd.tp_ipc_util import CollectiveFanout, SharedPoolChannel
+    L, half = 32, 64
+    cdev = device if backend == "nccl" else "cpu"
+    fan = CollectiveFanout(device=cdev)
+    exporter = importer = None
+    if rehearsal:   # the library's cpu device maps nothing and exports nothing: stand-ins that prove the control flow and that fds travel
+        exporter = lambda offs, gid: [os.memfd_create(f"kvc_rehearsal_{o}") for o in offs for _ in range(2 * L)]   # noqa: E731
+        seen = []
+        importer = lambda offs, fds, gid: seen.append((len(offs), sum(1 for fd in fds if os.fstat(fd).st_size == 0)))   # noqa: E731
+    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    vmm_ops.init_kvcached(device, PAGE, False)
+    out = {"ranks": world, "layers": L, "transport": f"{backend} broadcast of the offsets + all-reduce(min) of the status; one dmabuf fd per 2 MiB slot over SCM_RIGHTS"}
+    try:
+        ts = vmm_ops.create_kv_tensors(2 * half * PAGE, 8, device, L, 2, 0, False)     # int64 elements
+        chan = SharedPoolChannel(fan, exporter=exporter, importer=importer)
+        epp = PAGE // 8
+        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], dtype=torch.float64, device=cdev))   # noqa: E731
+        for k in (1, 8):
+            back, share, verify, ok_all = [], [], [], True
+            for it in range(6):
+                ids = [(it * k + j) % half for j in range(k)]
+                offs = [p * PAGE for p in ids]
+                sig = 0x5EED0000 + 977 * it + k
+                dist.barrier()
+                t0 = time.perf_counter()
+                if rank == 0:
+                    capi.map_to_kv_tensors(offs)
+                    if not rehearsal:
+                        for t in (ts[0], ts[L - 1]):                      # first K row and last V row of every page id
+                            for p in ids:
+                                t[p * epp] = sig + p
+                                t[(half + p) * epp + 5] = sig - p
+                        torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                tm = chan.share(offs)
+                t2 = time.perf_counter()
+                good = 1.0
+                if rank != 0 and not rehearsal:
+                    for t in (ts[0], ts[L - 1]):
+                        idx = torch.tensor([p * epp for p in ids] + [(half + p) * epp + 5 for p in ids], device=device)
+                        got = (t[idx] + 0).cpu().tolist()              # a gather kernel on THIS rank's GPU reads rank 0's pages
+                        good = good if got == [sig + p for p in ids] + [sig - p for p in ids] else 0.0
+                elif rank != 0:
+                    good = 1.0 if seen and seen[-1] == (k, k * 2 * L) else 0.0
+                t3 = time.perf_counter()
+                ok_all = ok_all and red(good, dist.ReduceOp.MIN) == 1.0
+                if rank != 0:
+                    capi.unmap_from_kv_tensors(offs)                      # the imports are dropped first ...
+                dist.barrier()
+                if rank == 0:
+                    capi.unmap_from_kv_tensors(offs)                      # ... then the owner gives the pages back
+                if it:                                                    # (the first round warms sockets and pools)
+                    back.append(t1 - t0)
+                    share.append(red(t2 - t1, dist.ReduceOp.MAX))
+                    verify.append(red(t3 - t2, dist.ReduceOp.MAX))
+            med = lambda v: round(statistics.median(v) * 1e3, 3)   # noqa: E731
+            out[f"{k}_page_ids"] = {"slots_2MiB": k * 2 * L, "rank0_back_ms_p50": med(back),
+                                    "export_ship_import_map_ms_p50_slowest_rank": med(share),
+                                    "ms_per_page_id": round(statistics.median(share) * 1e3 / k, 3),
+                                    "us_per_slot_per_peer": round(statistics.median(share) * 1e6 / (k * 2 * L) / max(1, world - 1), 2),
+                                    "peers_read_rank0_signature_ms_p50": med(verify), "signature_seen_by_every_peer": ok_all}
+        # which way the peers' imports went (each rank reports its own counters; rank 0 imports nothing)
+        mine = torch.tensor([float(capi.get_option(163)), float(capi.get_option(164))], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        out["imports_by_rank"] = [{"rank": r, "straight_into_KFD_and_DRM": int(e[0]), "through_the_runtime_ROCr": int(e[1])} for r, e in enumerate(every)]
+        gpus = torch.tensor([float(torch.cuda.current_device()) if not rehearsal else -1.0], dtype=torch.float64, device=cdev)
+        seen_gpus = [torch.zeros_like(gpus) for _ in range(world)]
+        dist.all_gather(seen_gpus, gpus)
+        distinct = len({int(g.item()) for g in seen_gpus})
+        out["gpus_used"] = distinct if not rehearsal else 0
+        out["what"] = ("cross-GPU: rank 0's pages are read by the peers over xGMI" if distinct == world and not rehearsal else
+                       "REHEARSAL on the library's cpu device: offsets and file descriptors travel, nothing is mapped" if rehearsal else
+                       f"REHEARSAL: {world} ranks share {distinct} GPU(s) - the export/ship/import/map machinery runs end to end, but nothing crosses xGMI")
+        chan.close()
+    finally:
+        vmm_ops.shutdown_kvcached()
+    return out
+
+
+def run_shared_pool_child(args):
+    """One rank of the leg, in a process of its own: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from the parent rank."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("KVC_BENCH_REHEARSAL") == "cpu"
+    backend = "gloo" if rehearsal else os.environ.get("KVC_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
+    if rehearsal:
+        device = "cpu"
+    else:
+        local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        device = f"cuda:{local_rank}"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    else:
+        dist.init_process_group(backend)
+    try:
+        out = shared_pool_leg(rank, world, device, backend, rehearsal)
+        out["rccl_world_size"] = dist.get_world_size()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def shared_pool_in_children(rank, world):
+    """Every rank of the N > 1 run starts ONE child that takes its place in the leg (own rendezvous port, own IPC name, the
+    same GPU): whatever happens there - the cross-GPU import has never run on this code before an 8-GPU node sees it - the
+    parent's measurement and its JSON line are safe. Rank 0 returns the leg's summary (or the error)."""
+    env = dict(os.environ)
+    port = int(env.get("MASTER_PORT", "29500"))
+    env["MASTER_PORT"] = str(port + 1 if port < 65000 else port - 1)
+    env["KVCACHED_IPC_NAME"] = f"kvc_bench_share_{port}"      # the same on every rank: the fd sockets live under one directory
+    env.pop("KVC_BENCH_TEST_FAIL_RANK", None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shared-pool-leg"], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "the shared-pool leg did not finish within 240 s"}
+    if rank != 0:
+        return None
+    js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not js:
+        return {"error": f"rank 0 of the leg exited with status {r.returncode}", "stderr_tail": (r.stderr or r.stdout)[-600:]}
+    return json.loads(js[-1])
+
+
+
 def ensure_built(local_rank: int) -> None:
     """The in-tree .so files normally travel with the repo; if they are missing, local rank 0 compiles them (hipcc,
     gfx950) while the other ranks wait. This only builds the product - there is no fallback to fall back to."""
@@ -454,6 +644,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     ensure_built(int(os.environ.get("LOCAL_RANK", "0")))
+    if args.shared_pool_leg:
+        return run_shared_pool_child(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -492,7 +684,8 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
-    # N = 1: before this process touches the GPU, a child runs the growth burst as the very first GPU work on the box -
+    # N = 1: before this process maps anything (it has only asked torch for the device), a child - a fresh process - runs the
+    # growth burst as the first allocation work on the box -
     # VRAM the kernel has not handed out since boot is cleared inside the allocation (~80 us per 2 MiB), memory that was
     # wiped on release is not: the same burst later in this run (variants) shows the other side. DESIGN.md §4.5.
     first_touch = None
@@ -540,6 +733,11 @@ def main():
         pages_by_rank = [int(e[1]) for e in sorted(everyone, key=lambda e: int(e[0]))]
         assert all(p == pages_by_rank[0] for p in pages_by_rank), f"ranks backed different amounts: {pages_by_rank}"
     main_sum = summarize(res, args.steps, world)
+    shared = None
+    if use_dist and world > 1 and os.environ.get("KVC_BENCH_SHARED_POOL", "1") != "0":
+        import torch.distributed as dist
+        dist.barrier()                       # every rank is past its timed region and has shut its allocator down
+        shared = shared_pool_in_children(rank, world)
 
     if rank == 0:
         line = {
@@ -579,9 +777,18 @@ def main():
             "host_us_per_call": main_sum["host_us_per_call"],
             "roofline": roofline_from(res["stats"]),
         }
+        if use_dist:
+            import torch.distributed as dist
+            line["rccl_world_size"] = dist.get_world_size()
+        if shared is not None:
+            line["shared_pool"] = shared
+            for k in (1, 8):
+                if isinstance(shared.get(f"{k}_page_ids"), dict):
+                    line["config"][f"shared_pool_{k}_page_ids_ms"] = shared[f"{k}_page_ids"]["export_ship_import_map_ms_p50_slowest_rank"]
         if world == 1 and not rehearsal:
             if first_touch is not None:
                 line["growth_burst_first_touch"] = first_touch
+                line["config"]["growth_burst_first_touch_GBps"] = first_touch.get("GBps")
             if not args.no_variants:
                 variants = {}
                 # name -> (mode, pool cap MB, compound layers, burst, prefault, backend, page, extra environment, steps)
@@ -632,6 +839,20 @@ def main():
                                 os.environ.pop(k, None)
                             else:
                                 os.environ[k] = v
+                try:   # the geometry engines use on ROCm, first-class: compat (the default) and lazy
+                    eg = engine_geometry(capi, device, args.mode)
+                    variants.update({k: v for k, v in eg.items() if isinstance(v, dict)})
+                    line["config"]["engine_lanes_per_buffer"] = eg.get("lanes_per_buffer")
+                    for n, key in ((1, "engine_llama3_8b_noncontig_1_page_id"), (8, "engine_llama3_8b_noncontig_8_page_ids"),
+                                   (64, "engine_llama3_8b_noncontig_64_page_ids")):
+                        line["config"][f"engine_{n}_page_ids_map_GBps"] = eg[key]["map_GBps"]
+                        line["config"][f"engine_{n}_page_ids_p50_map_ms"] = eg[key]["p50_map_ms"]
+                    other = "lazy" if args.mode == "compat" else "compat"
+                    for k, v in engine_geometry(capi, device, other).items():
+                        if isinstance(v, dict) and "straddling" not in k and "scattered" not in k:
+                            variants[k.replace("noncontig", f"noncontig_{other}")] = {kk: v[kk] for kk in ("p50_map_ms", "p50_unmap_ms", "map_GBps", "cycle_GBps", "ioctls_per_map_call")}
+                except Exception as e:
+                    variants["engine_llama3_8b_noncontig"] = {"error": str(e)[:300]}
                 line["variants"] = variants
                 # the reference's semantics (unbacked VA reads as zeros) next to the headline, not only among the variants
                 line["lazy_mode_GBps"] = variants.get("lazy_mode_opt_in", {}).get("GBps")

@@ -31,21 +31,25 @@ COUNTS = {21: "map.ioctls_issued", 22: "unmap.ioctls_issued", 23: "map.runs_foun
 
 
 def run(capi, n_ids, placement, iters, half_slots, layers, rng):
-    """placement: 'consecutive' (ids b..b+n-1, b not aligned to anything), 'aligned' (b a multiple of 64),
-    'scattered' (n ids drawn at random, as a churned free list yields them)."""
+    """placement:
+    'steady'     page ids b .. b+n-1 with b advancing by n and wrapping: after one sweep over the window every call finds the
+                 address space as its previous visit left it (what an engine that has been up for a while sees);
+    'straddling' the same runs shifted against the shape the previous unmap left: every call splits rest mappings;
+    'scattered'  n page ids drawn at random (a churned free list), most of them touched for the first time."""
     def ids_for(it):
-        if placement == "aligned":
-            b = (it * max(64, n_ids)) % (half_slots - max(64, n_ids) + 1)
-            b -= b % 64
+        if placement == "steady":
+            b = (it * n_ids) % (half_slots - half_slots % n_ids)
             return list(range(b, b + n_ids))
-        if placement == "consecutive":
+        if placement == "straddling":
             b = (it * n_ids * 3 + 5) % (half_slots - n_ids)
             return list(range(b, b + n_ids))
         return sorted(int(x) for x in rng.choice(half_slots, size=n_ids, replace=False))
 
-    warm = max(6, 2048 // (n_ids * layers * 2))
-    for it in range(warm):                                   # pool warm: extents of the shapes this pattern asks for exist
-        offs = [p * PAGE for p in ids_for(10_000 + it)]
+    # warm: one sweep over the window in the timed pattern (steady), a few cycles otherwise; the pool then holds buffers of
+    # the shapes this pattern asks for
+    warm = half_slots // n_ids if placement == "steady" else max(6, 2048 // (n_ids * layers * 2))
+    for it in range(warm):
+        offs = [p * PAGE for p in ids_for(it if placement == "steady" else 10_000 + it)]
         capi.map_to_kv_tensors(offs)
         capi.unmap_from_kv_tensors(offs)
     capi.flush_unmaps()
@@ -87,7 +91,7 @@ def main():
     ap.add_argument("--ids", default="1,8,64")
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--half-slots", type=int, default=512, help="page ids per region half (K or V of one layer)")
-    ap.add_argument("--placements", default="consecutive,aligned,scattered")
+    ap.add_argument("--placements", default="steady,straddling,scattered")
     args = ap.parse_args()
     os.environ.setdefault("KVCACHED_IPC_NAME", f"kvc_engine_{os.getpid()}")
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")

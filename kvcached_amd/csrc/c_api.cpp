@@ -202,6 +202,8 @@ int64_t kvc_get_option(int opt) {
     ExtentPool *p = ctx ? ctx->primary_pool() : nullptr;
     return p ? (int64_t)p->footprint().bad_releases : 0;
   }
+  case 163: return import_count(true);  // shared pool: pages of a peer imported straight into KFD + DRM (read-only)
+  case 164: return import_count(false); // ... and through the runtime's import (ROCr / HIP): the fallback, e.g. for a buffer on another GPU
   case 129: { // page ids of group 0 are backed as units (lanes: DESIGN.md §4.11), and how many lanes a buffer holds at most (0: no; read-only)
     try {
       return KvAllocator::initialized() ? (int64_t)KvAllocator::global(0)->lanes_per_extent() : 0;

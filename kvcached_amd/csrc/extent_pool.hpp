@@ -182,6 +182,7 @@ public:
     held_pages_ += n;
     ctr_->created += n * scale_;
     ++creations_;
+    demand_units_ += n;
     return take_pieces_locked(h, e, 0, n, out, recycled);
   }
 
@@ -364,6 +365,7 @@ public:
 
   // ---- accounting
   size_t creations() const { return creations_.load(); }
+  size_t demand_units() const { return demand_units_.load(); } // units created ON DEMAND (inside somebody's map call), ever
   size_t idle_pages() {
     std::lock_guard<std::mutex> g(mu_);
     return idle_pages_;
@@ -559,6 +561,7 @@ private:
   std::mutex mu_;
   uint64_t next_seq_ = 0, idle_stamp_ = 0;
   std::atomic<size_t> creations_{0}; // extents created on demand (not for the reserve)
+  std::atomic<size_t> demand_units_{0};
   size_t handed_out_since_clamp_ = 0;
   size_t recover_pages_ = 4096; // 8 GiB of 2 MiB pages handed out between two steps back up
   size_t held_pages_ = 0;   // everything obtained from the driver and not given back

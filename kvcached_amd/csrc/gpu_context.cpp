@@ -211,9 +211,14 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
 ExtentPool *GpuContext::lane_extents(size_t rows, size_t page_bytes) {
   if (rows < 2 || vmm_backend() != kVmmDrm || !DrmVm::instance().kfd_ready() || !DrmVm::instance().can_clear()) return nullptr;
   const size_t lane_bytes = rows * page_bytes;
-  // lanes per buffer: as many as fit KVCACHED_LANE_EXTENT_MB (default 1024: 8 page ids of the Llama-3-8B geometry, 128 MiB each)
+  // Lanes per buffer: KVCACHED_LANES_PER_BUFFER (default 8), as far as they fit KVCACHED_LANE_EXTENT_MB (default 1024: 8 page ids
+  // of the Llama-3-8B geometry, 128 MiB each). A buffer only goes back to the driver whole, so a page id that stays mapped - the
+  // PageAllocator keeps up to 10 freed ids mapped for reuse - pins the other lanes of its buffer: 8 lanes keep that to
+  // 7 lanes per straggler (64-lane buffers of a small geometry pinned 1 GiB each in tests/test_gpu_colocation.py), and
+  // beyond 8 the gain is small (the ioctl count per call is rows x ceil(ids / lanes): 64 for 8 page ids either way).
   const size_t cap_b = (size_t)std::max<int64_t>(1, env_i64("KVCACHED_LANE_EXTENT_MB", 1024)) << 20;
-  const unsigned k = (unsigned)std::min<size_t>(kMaxExtentPages, std::max<size_t>(1, cap_b / lane_bytes));
+  const size_t want_k = (size_t)std::min<int64_t>(kMaxExtentPages, std::max<int64_t>(1, env_i64("KVCACHED_LANES_PER_BUFFER", 8)));
+  const unsigned k = (unsigned)std::min<size_t>(want_k, std::max<size_t>(1, cap_b / lane_bytes));
   std::unique_ptr<ExtentPool> old;
   ExtentPool *p;
   {
@@ -264,6 +269,8 @@ void GpuContext::add_housekeeper(int delta) {
 }
 
 void GpuContext::housekeeping() {
+  std::unique_lock<std::mutex> one(hk_mu_, std::try_to_lock); // several PageAllocators' watchers may tick at once: one of them does the work
+  if (!one.owns_lock()) return;
   auto ps = all_pools();
   if (ps.empty()) return;
   (void)hipSetDevice(dev_);
@@ -288,14 +295,50 @@ void GpuContext::housekeeping() {
   // created here would be trimmed at the next tick, for ever)
   const size_t reserve_b = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   ExtentPool *primary = primary_pool_.load();
+  // The reserve follows demand. What a map call has to CREATE it pays for on its caller's thread - 2 us per
+  // buffer on VRAM the kernel has wiped, but ~50-80 us per 2 MiB on VRAM it has not handed out yet (cleared inside the
+  // allocation at 30-40 GB/s: profiles/r03_bench_n1.json growth_burst_first_touch, kfd_alloc 3.3 ms per 128 MiB). So when
+  // callers had to create memory during the last second, this thread creates AHEAD of them: up to twice that amount idle
+  // (never above the pool's cap or KVCACHED_PHYS_RESERVE_MAX_MB, default 16384), at up to 2 GiB per tick - ~20 GB/s, two
+  // thirds of what the kernel can clear - so that growth that goes on finds cleared memory. It is a target for creating,
+  // not a licence to keep: the decay floor stays the base reserve, so a second after the growth has stopped the target is
+  // the base again and what was made ahead and not used goes back like any idle memory (KVCACHED_POOL_IDLE_MS) - a
+  // co-located engine sees it return (tests/test_gpu_colocation.py).
+  size_t boost_units = 0, tick_units = 0;
+  if (primary) {
+    const size_t now_units = primary->demand_units();
+    if (demand_pool_ != primary) { // (another pool took over: start afresh)
+      demand_pool_ = primary;
+      demand_seen_ = now_units;
+      for (auto &d : demand_window_) d = 0;
+      demand_quiet_ticks_ = 0;
+      reserve_boost_units_ = 0;
+    }
+    const size_t delta = now_units - demand_seen_;
+    demand_seen_ = now_units;
+    demand_window_[demand_tick_++ % kDemandTicks] = delta;
+    size_t last_second = 0;
+    for (auto d : demand_window_) last_second += d;
+    demand_quiet_ticks_ = delta ? 0 : demand_quiet_ticks_ + 1;
+    const size_t max_units = std::min((size_t)std::max<int64_t>(0, options().pool_bytes.load()),
+                                      (size_t)std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MAX_MB", 16384)) << 20) / primary->page_bytes();
+    if (env_bool("KVCACHED_ADAPTIVE_RESERVE", true) && reserve_b > 0) {
+      reserve_boost_units_ = std::min(max_units, 2 * last_second); // (0 once a whole second has passed without a creation on anybody's path)
+    } else {
+      reserve_boost_units_ = 0;
+    }
+    boost_units = reserve_boost_units_;
+    tick_units = boost_units ? std::max<size_t>(1, (2048ull << 20) / primary->page_bytes()) : 0;
+  }
   for (auto *p : ps) {
     // the reserve belongs to the pool the engine's own pages come from (recorded at its first map call), not to the
     // exportable twin or to a pool a diagnostic happened to create
-    const size_t floor_pages = p == primary ? reserve_b / p->page_bytes() : 0;
-    if (idle_ms > 0) p->decay(now_ns(), idle_ms * 1000000ll, per_tick(p), floor_pages);
+    const size_t base_pages = p == primary ? reserve_b / p->page_bytes() : 0;
+    const size_t floor_pages = std::max(base_pages, p == primary ? boost_units : 0);
+    if (idle_ms > 0 && !(p == primary && boost_units)) p->decay(now_ns(), idle_ms * 1000000ll, per_tick(p), base_pages);
     // Growth into VRAM the kernel has not cleared yet costs ~80 us per 2 MiB inside the allocation (one SDMA ring,
     // ~30 GB/s: profiles/r02_create_cost.jsonl); this thread pays that ahead of time, off every caller's path.
-    if (floor_pages) p->refill_reserve(floor_pages, per_tick(p));
+    if (floor_pages) p->refill_reserve(floor_pages, std::max(per_tick(p), p == primary ? tick_units : 0));
   }
 }
 

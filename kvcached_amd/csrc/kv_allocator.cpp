@@ -2024,7 +2024,9 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
 // (huge, invalid) fd number and fails cleanly, after which the by-value form is used.
 namespace {
 std::atomic<int> g_import_convention{0}; // 0 unknown, 1 pointer to fd, 2 fd by value
+std::atomic<int64_t> g_imports_direct{0}, g_imports_runtime{0}; // pages imported straight into KFD + DRM / through ROCr or HIP
 }
+int64_t import_count(bool direct) { return direct ? g_imports_direct.load() : g_imports_runtime.load(); }
 static phys_handle_t import_posix_fd(int fd) {
   if (fd < 0 || fcntl(fd, F_GETFD) == -1) throw InvalidError("import of an invalid file descriptor");
   if (vmm_backend() == kVmmDrm && DrmVm::instance().kfd_ready() && env_bool("KVCACHED_DRM_KFD_IMPORT", true)) {
@@ -2033,13 +2035,16 @@ static phys_handle_t import_posix_fd(int fd) {
     // the local agent, is the fallback (hsa_amd_vmem_import_shareable_handle + map + set_access below).
     try {
       if (KVC_TEST_HOOK("FAIL_KFD_IMPORT")) throw GpuError("AMDKFD_IOC_IMPORT_DMABUF failed [injected]");
-      return DrmVm::instance().import_fd(fd);
+      const phys_handle_t h = DrmVm::instance().import_fd(fd);
+      ++g_imports_direct;
+      return h;
     } catch (const GpuError &e) {
       static std::atomic<bool> warned{false};
       if (!warned.exchange(true))
         KVC_LOG(LOG_WARNING, "direct import of a shared page failed (%s): importing through ROCr from now on", e.what());
     }
   }
+  ++g_imports_runtime;
   if (vmm_uses_rocr()) { // ROCr takes the dmabuf fd by value
     hsa_amd_vmem_alloc_handle_t hh{};
     HSA_CHECK(hsa_amd_vmem_import_shareable_handle(fd, &hh));

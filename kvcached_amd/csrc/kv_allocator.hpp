@@ -205,6 +205,11 @@ private:
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
   std::map<std::pair<size_t, size_t>, std::unique_ptr<ExtentPool>> lane_pools_; // key: (rows, page bytes)
   std::atomic<ExtentPool *> primary_pool_{nullptr};
+  // the reserve follows demand (housekeeping(), one thread): units created on callers' paths per tick over the last second
+  std::mutex hk_mu_;
+  static constexpr size_t kDemandTicks = 10;
+  ExtentPool *demand_pool_ = nullptr;
+  size_t demand_seen_ = 0, demand_window_[kDemandTicks] = {}, demand_tick_ = 0, demand_quiet_ticks_ = 0, reserve_boost_units_ = 0;
   ExtentDriver make_driver(size_t unit_bytes, bool exportable, bool aliases);
   std::vector<ExtentPool *> all_pools();
   KfdTlbFlush kfd_flush_;
@@ -393,5 +398,6 @@ private:
 void mem_get_info(size_t *free_b, size_t *total_b);
 void set_mem_info_override(size_t free_b, size_t total_b);
 void device_synchronize();
+int64_t import_count(bool direct); // shared pool: a peer's pages imported straight into KFD + DRM / through the runtime (ROCr, HIP)
 
 } // namespace kvc

@@ -178,11 +178,15 @@ def start_collective_worker(group=None, src: int = 0, device: Optional[str] = No
     interleave with the engine's. The src rank keeps the fan-out for its socket listener to relay with; every other
     rank parks a daemon thread in the collective, applying what src broadcasts, until stop_collective_worker()."""
     global _collective, _follower
-    fan = CollectiveFanout(group=group, src=src, device=device)
+    fan = CollectiveFanout(group=group, src=src, device=device, park_on_host=True)
     if fan.rank == src:
         _collective = fan
     else:
         def follow():
+            # a new thread's current device is 0: bind it to the GPU the fan-out's buffers live on, or the stream this
+            # thread synchronises (and the RCCL work it enqueues) would be another GPU's
+            if fan._on_gpu:
+                fan._torch.cuda.set_device(fan._torch.device(fan.device))
             while fan.serve_one():
                 pass
         _follower = threading.Thread(target=follow, name="kvcached-tp-follower", daemon=True)
@@ -396,7 +400,7 @@ def share_mapped_slots(tp_size: int, offsets: List[int], pp_rank: int = 0, group
 
 
 # ------------------------------------------------------------------ collective transport
-CMD_MAP, CMD_UNMAP, CMD_CREATED, CMD_STOP = 1, 2, 3, 4
+CMD_MAP, CMD_UNMAP, CMD_CREATED, CMD_STOP, CMD_SHARE = 1, 2, 3, 4, 5
 
 
 class CollectiveFanout:
@@ -406,7 +410,12 @@ class CollectiveFanout:
 
     MAX_OFFSETS = 4093  # header + payload = 4096 int64 = 32 KiB, one fixed-size broadcast
 
-    def __init__(self, group=None, src: int = 0, device: Optional[str] = None):
+    def __init__(self, group=None, src: int = 0, device: Optional[str] = None, park_on_host: bool = False):
+        """park_on_host: the non-src ranks wait for the NEXT command in a helper thread (start_collective_worker). A rank
+        parked inside an RCCL broadcast has that collective sitting enqueued on its GPU, where any device-wide
+        synchronisation (torch.cuda.synchronize, the library's own hipDeviceSynchronize) would wait for the scheduler's next
+        KV command; so a one-word gloo broadcast wakes the followers first and the RCCL broadcast is only entered when src
+        has a message in hand."""
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -426,6 +435,12 @@ class CollectiveFanout:
         self._stage_np = self._stage.numpy()
         self._status_host = torch.zeros(1, dtype=torch.int64, pin_memory=on_gpu) if on_gpu else self._status
         self._on_gpu = on_gpu
+        self._wake_group = None
+        if park_on_host and on_gpu and self.world_size > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            # (every member of the TP group calls this constructor; no other process has to)
+            self._wake_group = dist.new_group(ranks=ranks, backend="gloo", use_local_synchronization=True)
+            self._wake = torch.zeros(1, dtype=torch.int64)
 
     def _exchange(self, cmd: int, offsets: Sequence[int], group_id: int) -> Tuple[int, int, List[int]]:
         torch, dist = self._torch, self._dist
@@ -438,12 +453,14 @@ class CollectiveFanout:
             st[3:3 + n] = offsets
             if self._on_gpu:
                 self._buf[:3 + n].copy_(self._stage[:3 + n], non_blocking=True)
+        if self._wake_group is not None:   # host-side wake-up: nobody waits inside a GPU collective for a command that is not there yet
+            dist.broadcast(self._wake, src=dist.get_global_rank(self.group, self.src) if self.group else self.src, group=self._wake_group)
         dist.broadcast(self._buf, src=dist.get_global_rank(self.group, self.src) if self.group else self.src,
                        group=self.group)
         if self._on_gpu and self.rank != self.src:
             # the payload length is not known before the copy: bring the whole (32 KiB) message over, once
             self._stage.copy_(self._buf, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self._buf.device).synchronize()   # the stream of the buffer's GPU, whatever this thread's current device is
         st = self._stage_np
         n = int(st[2])
         return int(st[0]), int(st[1]), st[3:3 + n].tolist()
@@ -500,3 +517,108 @@ class CollectiveFanout:
 
     def unmap_from_kv_tensors(self, offsets: Sequence[int] = (), group_id: int = 0) -> List[int]:
         return self.run(CMD_UNMAP, offsets, group_id)
+
+
+class SharedPoolChannel:
+    """The shared pool between the ranks of ONE torch.distributed group (north star: rank 0 creates pages, peers map them over
+    xGMI; no counterpart in the reference, whose ranks each back their own pages - kvcached/tp_ipc_util.py:173-192 only
+    fans offsets out). SPMD: every rank calls share() together.
+      * the METADATA - (group id, offsets) - travels through the group's collective: one RCCL broadcast from `src`
+        (CollectiveFanout's message), and one all-reduce(min) of a status word at the end;
+      * the HANDLES are POSIX file descriptors (hipMemExportToShareableHandle / AMDKFD_IOC_EXPORT_DMABUF) and cannot travel
+        through RCCL: src ships them with SCM_RIGHTS over one persistent Unix socket per peer
+        (<socket dir>/[pp<k>/]fds<rank>.sock, next to the workers' command sockets).
+    `exporter(offsets, group_id) -> fds` and `importer(offsets, fds, group_id)` default to the library's
+    kvc_export_mapped_slots / kvc_map_imported_slots; tests and the CPU rehearsal of bench.py pass stand-ins."""
+
+    def __init__(self, fan: "CollectiveFanout", pp_rank: int = 0, exporter=None, importer=None, timeout: float = 60.0):
+        self.fan, self.rank, self.src, self.world = fan, fan.rank, fan.src, fan.world_size
+        if exporter is None or importer is None:
+            from kvcached_amd import capi
+            exporter = exporter or (lambda offs, gid: capi.export_mapped_slots(offs, gid))
+            importer = importer or (lambda offs, fds, gid: capi.map_imported_slots(offs, fds, gid))
+        self._export, self._import = exporter, importer
+        self._peers: Dict[int, socket.socket] = {}
+        self._up: Optional[socket.socket] = None
+        base = os.path.dirname(get_worker_socket_path(0, pp_rank))
+        os.makedirs(base, exist_ok=True)
+        path = lambda r: os.path.join(base, f"fds{r}.sock")   # noqa: E731
+        server = None
+        if self.rank != self.src:
+            if os.path.exists(path(self.rank)):
+                os.remove(path(self.rank))
+            server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            server.bind(path(self.rank))
+            server.listen(1)
+            server.settimeout(timeout)
+        fan.run(CMD_CREATED, (), 0, raise_on_failure=False)   # (a barrier: every peer listens before src connects)
+        if self.rank == self.src:
+            for r in range(self.world):
+                if r != self.src:
+                    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                    s.settimeout(timeout)
+                    s.connect(path(r))
+                    self._peers[r] = s
+        else:
+            self._up, _ = server.accept()
+            self._up.settimeout(timeout)
+            server.close()
+            os.remove(path(self.rank))
+
+    def share(self, offsets: Sequence[int] = (), group_id: int = 0) -> Dict[str, float]:
+        """src has just backed `offsets` with exportable pages; afterwards every other rank shows the SAME physical pages at the
+        same offsets. Returns this rank's timings (seconds): export, ship (src) / import+map (peers), total. Raises on every
+        rank if any rank failed."""
+        import time
+        t0 = time.perf_counter()
+        fds: List[int] = []
+        ok, err = True, None
+        t_export = t_ship = t_import = 0.0
+        try:
+            if self.rank == self.src:
+                fds = list(self._export(list(offsets), group_id))
+                t_export = time.perf_counter() - t0
+        except Exception as e:   # the others are waiting in the broadcast: tell them there is nothing to come
+            ok, err = False, e
+        _, gid, offs = self.fan._exchange(CMD_SHARE, offsets if ok else (), group_id)
+        try:
+            t1 = time.perf_counter()
+            if self.rank == self.src:
+                for s in self._peers.values():   # (also when the export failed: the peers are waiting for this header)
+                    send_msg(s, {"n_fds": len(fds) if ok else 0, "failed": not ok})
+                    if ok and fds:
+                        send_fds(s, {}, fds)
+                t_ship = time.perf_counter() - t1
+            else:
+                head = recv_msg(self._up)
+                got: List[int] = []
+                try:
+                    if head.get("failed"):
+                        raise RuntimeError("the source rank could not export its pages")
+                    if head["n_fds"]:
+                        _, got = recv_fds(self._up, head["n_fds"])
+                        self._import(offs, got, gid)
+                    elif offs:
+                        raise RuntimeError("no handles came with the offsets")
+                finally:
+                    for fd in got:
+                        os.close(fd)
+                t_import = time.perf_counter() - t1
+        except Exception as e:
+            ok, err = False, err or e
+        finally:
+            for fd in fds:
+                os.close(fd)
+        try:
+            self.fan._finish(ok)
+        except RuntimeError:
+            raise RuntimeError(f"sharing {len(offs)} offsets failed on some rank" + (f" (this one: {err})" if err else "")) from err
+        return {"export_s": t_export, "ship_s": t_ship, "import_map_s": t_import, "total_s": time.perf_counter() - t0}
+
+    def close(self) -> None:
+        for s in list(self._peers.values()) + ([self._up] if self._up else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._up = {}, None

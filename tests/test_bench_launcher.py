@@ -32,6 +32,18 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     # whole-job value: both ranks' bytes over the slowest rank's time
     per_gpu = line["config"]["per_gpu_bytes_per_step"]
     assert abs(line["value"] - 2 * per_gpu / (line["ms_per_step"] * 1e-3) / 1e9) / line["value"] < 0.02
+    # the shared-pool leg (BASELINE config 4) rides in the same line: rank 0's offsets reached rank 1 through the collective, one
+    # file descriptor per 2 MiB slot through SCM_RIGHTS, both ranks agreed on the result - on the cpu device nothing is mapped,
+    # and the line says so
+    sp = line["shared_pool"]
+    assert "error" not in sp, sp
+    assert sp["ranks"] == 2 and sp["rccl_world_size"] == 2 and "REHEARSAL" in sp["what"]
+    for k in (1, 8):
+        leg = sp[f"{k}_page_ids"]
+        assert leg["slots_2MiB"] == k * 64 and leg["signature_seen_by_every_peer"] is True
+        assert leg["export_ship_import_map_ms_p50_slowest_rank"] > 0
+    assert line["config"]["shared_pool_8_page_ids_ms"] == sp["8_page_ids"]["export_ship_import_map_ms_p50_slowest_rank"]
+    assert line["rccl_world_size"] == 2
 
 
 def test_under_a_launcher_it_does_not_spawn_again():

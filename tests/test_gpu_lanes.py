@@ -63,7 +63,7 @@ def _check(views, ids, base):
 def test_page_ids_are_backed_and_given_back_as_units(lanes, compat):
     ops, capi, views = _engine(lanes, layers=4, ids_per_half=64, compat=compat)
     R = len(views)
-    assert R == 8 and capi.get_option(129) >= 8          # lanes in use, up to 8 (1 GiB / (8 rows x 2 MiB) caps at 64 -> 64; at least 8)
+    assert R == 8 and capi.get_option(129) == 8          # page ids are backed by lanes, 8 to a buffer at most
     capi.reset_stats()                                   # once: the ledger at the end counts from here
     snap = lambda: (capi.get_stats()["pages_mapped"], capi.get_option(130 + 21), capi.get_option(130 + 23))   # noqa: E731  pages, ioctls, runs
     delta = lambda a, b: tuple(y - x for x, y in zip(a, b))                                                     # noqa: E731

@@ -429,6 +429,53 @@ def test_the_physical_reserve_is_created_ahead_of_time_and_serves_a_growth_burst
     assert st["handles_created"] == st["handles_released"]
 
 
+def test_the_reserve_follows_demand(monkeypatch):
+    """what a map call has to CREATE is paid on its caller's thread (2 us per buffer on wiped VRAM, 50-80 us per
+    2 MiB on VRAM the kernel has not handed out yet). While callers have to create memory, the housekeeping thread creates
+    ahead of them - up to twice what the last second asked for - so growth that goes on finds memory that is there already;
+    a second after the growth has stopped the target is the base reserve again and the surplus goes back to the driver like
+    any idle memory, where a co-located engine can have it."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "256")            # the base reserve: 8 page ids of this geometry (16 rows x 2 MiB)
+    monkeypatch.setenv("KVCACHED_POOL_IDLE_MS", "200")
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)          # the watcher thread is the housekeeper
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    capi.reset_stats()
+    try:
+        L = 8
+        vmm_ops.create_kv_tensors(512 * T.PAGE * 2, 1, DEV, L, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=512 * 64, block_size=16, cell_size=2048, num_layers=L)
+        assert m._post_init_done.wait(10)
+        if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+            pytest.skip("the reserve is pre-created with the drm backend and pages straight from KFD")
+        rows = 2 * L
+        time.sleep(0.5)
+        idle = lambda: capi.get_option(capi.OPT_POOL_HELD_PAGES) - capi.get_option(capi.OPT_POOL_OUT_PAGES)   # noqa: E731
+        burst = 96                                                   # page ids: 96 x 16 x 2 MiB = 3 GiB, far beyond the 256 MiB base
+        before = capi.get_stats()["handles_created"]
+        first = m.alloc(burst * 64)
+        created_first = capi.get_stats()["handles_created"] - before
+        assert created_first >= (burst - 20) * rows                  # the first burst had to create (almost) all of it on the caller's path
+        time.sleep(0.7)                                               # a few ticks: the thread creates ahead, towards 2 x the burst
+        assert idle() >= burst * rows, idle()
+        before = capi.get_stats()["handles_created"]
+        second = m.alloc(burst * 64)                                 # the growth goes on: served from memory made ahead of it
+        created_second = capi.get_stats()["handles_created"] - before
+        assert created_second <= created_first // 8, (created_first, created_second)
+        m.free(first)
+        m.free(second)
+        m.trim()
+        time.sleep(4.0)                                               # the growth has stopped: one second later the target is the base again,
+        assert idle() <= 4 * 256 // 2, idle()                       # and the idle windows (200 ms, 512 MiB per tick) have returned the rest
+        del m
+    finally:
+        vmm_ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_golden_trace_with_async_unmap(monkeypatch):
     """Bookkeeping is synchronous, so the reference's golden trace (block ids, page offsets, counters) is still
     bit-exact with KVC_OPT_ASYNC_UNMAP on; after a flush the physical ledger matches the synchronous run."""
