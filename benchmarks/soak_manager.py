@@ -37,10 +37,15 @@ def main():
                     help="every 32 ops a kernel reads one word of EVERY slot of every region, backed or not (needs a mode in which "
                          "unbacked VA does not fault: PRT or zero aliases): if a PRT 'miss' were ever cached by the GPU, a slot "
                          "backed afterwards would be shadowed by it and its signatures would come back wrong")
+    ap.add_argument("--unmap-invalidation-us", type=int, default=None,
+                    help="KVCACHED_UNMAP_INVALIDATION_US: compat mode's relaxed form - the invalidation an unmap owes trails the call by at "
+                         "most this long, the pages wait for it un-scrubbed and un-offered")
     ap.add_argument("--no-prt", action="store_true", help="compat mode with the zero extent behind unbacked VA instead of PRT (KVCACHED_PRT=false)")
     args = ap.parse_args()
     if args.no_prt:
         os.environ["KVCACHED_PRT"] = "false"
+    if args.unmap_invalidation_us is not None:
+        os.environ["KVCACHED_UNMAP_INVALIDATION_US"] = str(args.unmap_invalidation_us)
     if args.pool_mb is not None:
         os.environ["KVCACHED_PHYS_POOL_MB"] = str(args.pool_mb)
     if args.extent_pages is not None:
@@ -81,6 +86,7 @@ def main():
     m = kcm.KVCacheManager(num_blocks=num_blocks, block_size=BLOCK_TOKENS, cell_size=CELL, num_layers=LAYERS)
     assert m._post_init_done.wait(30)
     capi_prt = capi.get_option(128)
+    lanes = capi.get_option(129)
     ipc = m.page_allocator._ipc_name()
     full_limit = per_layer * LAYERS
     rng = np.random.default_rng(args.seed)
@@ -231,6 +237,8 @@ def main():
                                  "what": "physical pages held from the driver (mapped + pooled + free pieces of partly used chunks) per mapped page"},
                max_extent_pages=max_extent_pages, prt=bool(capi_prt), pool_mb=os.environ.get("KVCACHED_PHYS_POOL_MB", "default (16384)"),
                backend=backend, seconds=args.seconds, async_unmap=args.async_unmap, compat=args.compat,
+               unmap_invalidation_us=int(os.environ.get("KVCACHED_UNMAP_INVALIDATION_US", "0")), lanes_per_buffer=int(lanes),
+               tlb_shootdowns=st["tlb_shootdowns"],
                prealloc=args.prealloc, **counts, wrong_words=bad, inuse_pages_at_end=inuse,
                pages_mapped=st["pages_mapped"], pages_unmapped=st["pages_unmapped"],
                handles_created=end["handles_created"], handles_reused=end["handles_reused"], handle_leak=leak)

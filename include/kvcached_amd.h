@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KVC_ABI_VERSION 4
+#define KVC_ABI_VERSION 5
 
 enum {
   KVC_OK = 0,
@@ -116,6 +116,15 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  *                              KVCACHED_PHYS_CHUNK_PAGES=k (default 1) allocates that memory in chunks of k pages and
  *                              maps runs of adjacent slots with one ioctl (opt-in).
  *                              DESIGN.md §4.6/§4.7.
+ *   KVC_OPT_UNMAP_INVALIDATION_US  compat regions only (env KVCACHED_UNMAP_INVALIDATION_US). 0 (default): kvc_unmap_from_kv_tensors
+ *                          invalidates the GPU TLBs before it returns - a freed address reads as zeros from that moment on.
+ *                          T > 0: the invalidation may trail the call by at most T microseconds; it is performed by the
+ *                          library's own thread, or absorbed by the invalidation of the next map batch if that comes
+ *                          first (one invalidation per free+alloc cycle instead of two). Until it has happened the freed
+ *                          pages are neither zeroed nor on offer (order: page tables, invalidation, zero fill, pool), so
+ *                          no stale translation can ever reach a page somebody else holds; what is relaxed is only that a
+ *                          read of a FREED address may still see the old contents for up to T microseconds. Still
+ *                          stricter than the reference, which never invalidates (csrc/ftensor.cpp:120-140).
  *   KVC_OPT_ASYNC_UNMAP    1 = kvc_unmap_from_kv_tensors only marks the slots and queues them; a reclaimer thread
  *                              of the library carries out hipMemUnmap + invalidation + handle recycling in small
  *                              chunks, yielding to map calls. A slot that is mapped again before its turn is kept
@@ -129,7 +138,8 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  * footprint, 125/126 pages zeroed on their way back / handed out without a fill of their own, 127 pages of the zero
  * extent, 128 PRT behind unbacked VA, 130-149 host nanoseconds of the map / unmap calls by segment (bench.py). */
 enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
-       KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6, KVC_OPT_ASYNC_UNMAP = 7 };
+       KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6, KVC_OPT_ASYNC_UNMAP = 7,
+       KVC_OPT_UNMAP_INVALIDATION_US = 8 };
 int kvc_set_option(int opt, int64_t value);
 int64_t kvc_get_option(int opt);
 int kvc_flush_unmaps(void); /* wait until every queued (async) unmap has been carried out */

@@ -26,6 +26,7 @@ KVC_OK, KVC_E_INVALID, KVC_E_GPU, KVC_E_NO_PAGES, KVC_E_RUNTIME, KVC_E_NO_GPU, K
 KVC_E_NOT_CREATED = -7
 OPT_ZERO_BACKFILL, OPT_ZERO_FILL, OPT_POOL_BYTES, OPT_PROFILE, OPT_TLB_SHOOTDOWN, OPT_DEFER_UNMAP_SHOOTDOWN = 1, 2, 3, 4, 5, 6
 OPT_ASYNC_UNMAP = 7
+OPT_UNMAP_INVALIDATION_US = 8   # compat: the invalidation an unmap owes may trail the call by this many microseconds (0: inside the call)
 OPT_FILL_VARIANT, OPT_COMPACT_VARIANT = 100, 101  # tuning only
 # read-only: the VMM backend in effect after init's self tests (0 hip, 2 hybrid, 3 drm), and whether physical
 # pages come straight from KFD (drm backend only)

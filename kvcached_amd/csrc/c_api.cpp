@@ -123,6 +123,12 @@ int kvc_set_option(int opt, int64_t value) {
     if (!value) KvAllocator::flush_all_unmaps(); // switching off: nothing may stay queued
     options().async_unmap = value;
     break;
+  case KVC_OPT_UNMAP_INVALIDATION_US:
+    if (value <= 0) { // switching off: nothing may stay parked behind an invalidation nobody is in a hurry for
+      if (GpuContext *ctx = KvAllocator::gpu()) ctx->flush_limbo();
+    }
+    options().deferred_unmap_flush_us = value < 0 ? 0 : value;
+    break;
   case 102: options().access_run_slots = value; break; // tuning only
   case 103: options().zero_alias_fanout = value; break; // takes effect at the next create_kv_tensors
   case 105: options().fill_chunk_slots = value < 1 ? 1 : value; break; // tuning only
@@ -144,6 +150,7 @@ int64_t kvc_get_option(int opt) {
   case KVC_OPT_TLB_SHOOTDOWN: return options().tlb_shootdown;
   case KVC_OPT_DEFER_UNMAP_SHOOTDOWN: return options().defer_unmap_shootdown;
   case KVC_OPT_ASYNC_UNMAP: return options().async_unmap;
+  case KVC_OPT_UNMAP_INVALIDATION_US: return options().deferred_unmap_flush_us;
   case 102: return options().access_run_slots;
   case 103: return options().zero_alias_fanout;
   case 105: return options().fill_chunk_slots;

@@ -81,6 +81,11 @@ GpuContext::~GpuContext() {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
+  try {
+    flush_limbo(); // parked pages go home before their pools go
+  } catch (...) {
+    (void)hipGetLastError();
+  }
   if (scrub_stream_) (void)hipStreamSynchronize(scrub_stream_); // no fill may be running on an alias that is about to go
   primary_pool_.store(nullptr);
   extent_pools_[0].clear(); // idle extents go back to the driver (after the invalidation they may still be owed)
@@ -202,7 +207,10 @@ ExtentPool *GpuContext::extents(size_t page_bytes, bool exportable) {
     }
     p = it->second.get();
   }
-  old.reset();
+  if (old) {
+    flush_limbo(); // (a parked finisher holds a pointer to its pool)
+    old.reset();
+  }
   p->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   p->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
   return p;
@@ -234,7 +242,10 @@ ExtentPool *GpuContext::lane_extents(size_t rows, size_t page_bytes) {
     }
     p = slot.get();
   }
-  old.reset();
+  if (old) {
+    flush_limbo();
+    old.reset();
+  }
   p->set_cap_bytes((size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   p->set_waste_frac((double)std::max<int64_t>(0, options().extent_waste_pct.load()) / 100.0);
   return p;
@@ -251,11 +262,16 @@ std::vector<ExtentPool *> GpuContext::all_pools() {
 }
 
 void GpuContext::drain_pools() {
+  try {
+    flush_limbo();
+  } catch (...) {
+    (void)hipGetLastError();
+  }
   for (auto *p : all_pools()) p->drain(0);
 }
 
 size_t GpuContext::idle_pool_bytes() {
-  size_t b = 0;
+  size_t b = limbo_bytes_.load(); // (unmapped, on their way back to their pool: ours to reuse a moment from now)
   for (auto *p : all_pools()) b += p->idle_bytes();
   return b;
 }
@@ -665,18 +681,60 @@ int64_t GpuContext::unique_block_ids(const int64_t *idx, size_t n, int64_t tpb, 
 }
 
 void GpuContext::ensure_flushed() {
-  std::lock_guard<std::mutex> g(flush_mu_);
-  if (tlb_stale().load()) do_shootdown();
+  {
+    std::lock_guard<std::mutex> g(flush_mu_);
+    if (tlb_stale().load()) do_shootdown();
+  }
+  drain_limbo(); // (outside flush_mu_: a finisher may release memory to the driver, which asks for the flush lock itself)
 }
 
-void GpuContext::request_async_flush() {
+void GpuContext::request_async_flush(int64_t within_us) {
   {
     std::lock_guard<std::mutex> g(fl_mu_);
     if (fl_stop_) return;
     if (!flusher_.joinable()) flusher_ = std::thread([this] { flusher_loop(); });
     fl_kick_ = true;
+    if (within_us > 0) {
+      const int64_t d = now_ns() + within_us * 1000;
+      fl_deadline_ns_ = fl_deadline_ns_ ? std::min(fl_deadline_ns_, d) : d;
+    }
   }
   fl_cv_.notify_one();
+}
+
+void GpuContext::park(uint64_t epoch, size_t bytes, std::function<void()> finish) {
+  std::lock_guard<std::mutex> g(limbo_mu_);
+  limbo_.push_back(Parked{epoch, bytes, std::move(finish)});
+  limbo_bytes_ += bytes;
+}
+
+void GpuContext::drain_limbo() {
+  if (!limbo_bytes_.load()) return;
+  for (;;) {
+    Parked p;
+    {
+      std::lock_guard<std::mutex> g(limbo_mu_);
+      if (limbo_.empty() || !flushed_through(limbo_.front().epoch)) return; // (epochs are stamped in order: the front is the oldest)
+      p = std::move(limbo_.front());
+      limbo_.pop_front();
+    }
+    try {
+      p.finish();
+    } catch (const std::exception &e) {
+      KVC_LOG(LOG_ERROR, "giving parked pages back failed: %s", e.what());
+    }
+    limbo_bytes_ -= std::min(p.bytes, limbo_bytes_.load());
+  }
+}
+
+void GpuContext::flush_limbo() {
+  uint64_t newest = 0;
+  {
+    std::lock_guard<std::mutex> g(limbo_mu_);
+    if (!limbo_.empty()) newest = limbo_.back().epoch;
+  }
+  if (newest) ensure_flushed_through(newest);
+  drain_limbo();
 }
 
 void GpuContext::flusher_loop() {
@@ -694,7 +752,20 @@ void GpuContext::flusher_loop() {
     // been active for 150 us, or after 2 ms at the latest (an engine that frees and allocates in one scheduler step
     // gets its alloc through first; a tight loop is invalidated every few iterations instead of behind every one).
     const int64_t t0 = now_ns();
-    while (foreground_busy() && now_ns() - t0 < 2000000) std::this_thread::sleep_for(std::chrono::microseconds(40));
+    for (;;) {
+      int64_t deadline;
+      {
+        std::lock_guard<std::mutex> g(fl_mu_);
+        deadline = fl_deadline_ns_;
+      }
+      const int64_t now = now_ns();
+      if (!foreground_busy() || now - t0 >= 2000000 || (deadline && now >= deadline)) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(deadline ? 20 : 40));
+    }
+    {
+      std::lock_guard<std::mutex> g(fl_mu_);
+      fl_deadline_ns_ = 0;
+    }
     try {
       ensure_flushed();
     } catch (const std::exception &e) {
@@ -708,8 +779,11 @@ void GpuContext::flusher_loop() {
 // Unconditional invalidation. Serialised with ensure_flushed(): the flag is cleared when an invalidation STARTS, so
 // whoever finds it clear must be able to rely on that invalidation having finished - both take flush_mu_.
 void GpuContext::tlb_shootdown() {
-  std::lock_guard<std::mutex> g(flush_mu_);
-  do_shootdown();
+  {
+    std::lock_guard<std::mutex> g(flush_mu_);
+    do_shootdown();
+  }
+  drain_limbo();
 }
 
 void GpuContext::ensure_flushed_through(uint64_t epoch) {
@@ -720,6 +794,7 @@ void GpuContext::ensure_flushed_through(uint64_t epoch) {
     if (flushed_through(epoch)) break;
     do_shootdown();
   }
+  drain_limbo();
 }
 
 void GpuContext::do_shootdown() {

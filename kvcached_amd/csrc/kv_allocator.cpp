@@ -382,6 +382,7 @@ void KvAllocator::init(const std::string &dev_str, size_t page_size, bool contig
   options().phys_reserve_bytes = std::max<int64_t>(0, env_i64("KVCACHED_PHYS_RESERVE_MB", 2048)) << 20;
   options().scrub_on_release = env_bool("KVCACHED_SCRUB_ON_RELEASE", true) ? 1 : 0;
   options().map_waits_for_all_flushes = env_bool("KVCACHED_MAP_WAITS_FOR_ALL_FLUSHES", false) ? 1 : 0;
+  options().deferred_unmap_flush_us = std::max<int64_t>(0, env_i64("KVCACHED_UNMAP_INVALIDATION_US", 0));
   {
     const char *ms = std::getenv("KVCACHED_MAP_SHOOTDOWN");
     options().map_shootdown_always = (ms && std::string(ms) == "always") ? 1 : 0;
@@ -613,6 +614,7 @@ void KvAllocator::flush_all_unmaps() {
   if (GpuContext *ctx = gpu()) { // ... and no invalidation is left owed or in flight, no page still being zeroed
     ctx->bind();
     ctx->ensure_flushed();
+    ctx->flush_limbo();
     ctx->wait_all_scrubs();
   }
 }
@@ -1324,6 +1326,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
         dirty_tlb = true;
         need_epoch = ctx->next_flush_epoch(); // (the page's old address was live a moment ago: conservative)
       } else {
+        if (ctx->limbo_bytes()) ctx->flush_limbo(); // pages of an earlier unmap wait for their invalidation: have it now rather than create
         (void)pool->acquire_run(1, &ph, &recycled, true);
       }
       phys_handle_t h = ph.h;
@@ -1385,6 +1388,10 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
           if (n == 0 && steal_pending(ps, &got[0])) {
             n = 1; // (its unmap has set tlb_stale: flushed before the fill)
             need_epoch = ctx->next_flush_epoch();
+          }
+          if (n == 0 && ctx->limbo_bytes()) { // pages of an earlier unmap wait for their invalidation: have it now rather than create
+            ctx->flush_limbo();
+            n = pool->acquire_run(end - at, got.data(), &recycled, false);
           }
           if (n == 0) n = pool->acquire_run(end - at, got.data(), &recycled, true);
           const int64_t t2 = now_ns();
@@ -1667,6 +1674,25 @@ void KvAllocator::unmap_finish(Unmapped &u, bool may_defer_shootdown) {
   //     caller's free() and, unless an alloc follows within that tick, reaches nobody's critical path
   //     (KVCACHED_ASYNC_SHOOTDOWN, on by default; one page id: free() 0.6 -> 0.2 ms).
   SegTimer sg;
+  const int64_t trail_us = options().deferred_unmap_flush_us.load();
+  if (trail_us > 0 && u.any_backfilled && u.imported.empty() && may_defer_shootdown && !u.own.empty()) {
+    // compat, relaxed (KVCACHED_UNMAP_INVALIDATION_US): the invalidation trails the call by at most trail_us - performed by
+    // the context's thread, or absorbed by the next map batch's own. The pages wait for it un-scrubbed and un-offered.
+    auto own = std::make_shared<std::vector<Phys>>(std::move(u.own));
+    const size_t ps = u.page_size;
+    ctx->park(u.epoch, own->size() * ps, [ctx, pool, own, ps]() {
+      uint64_t ticket = 0;
+      if (options().zero_fill.load() && options().scrub_on_release.load() && pool->multi_page()) {
+        std::vector<uint64_t> addrs(own->size());
+        if (pool->scrub_addresses(own->data(), own->size(), addrs.data())) ticket = ctx->scrub(addrs.data(), addrs.size(), ps);
+      }
+      pool->release_batch(own->data(), own->size(), ticket);
+    });
+    ctx->request_async_flush(trail_us);
+    sg.mark(16);
+    stats().pages_unmapped += u.n;
+    return;
+  }
   const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
   if (u.any_backfilled || !u.imported.empty() || !may_defer_shootdown || !defer) {
     // (starting it on the context's thread and overlapping the scrub launch and the pool with it was tried: the thread
@@ -1805,6 +1831,10 @@ bool KvAllocator::try_map_lanes(const offset_t *offsets, size_t n) {
         bool recycled = false;
         const int64_t t1 = now_ns();
         c.k = pool->acquire_run(end - at, c.lane, &recycled, false);
+        if (!c.k && ctx->limbo_bytes()) { // pages of an earlier unmap wait for their invalidation: have it now rather than create
+          ctx->flush_limbo();
+          c.k = pool->acquire_run(end - at, c.lane, &recycled, false);
+        }
         if (!c.k) c.k = pool->acquire_run(end - at, c.lane, &recycled, true);
         const int64_t t2 = now_ns();
         sg.mark(3);
@@ -1987,6 +2017,28 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
     }
   sg.mark(15);
   // the invalidation: inside the call where unbacked VA promises zeros (compat), behind it otherwise (see unmap_finish)
+  const int64_t trail_us = options().deferred_unmap_flush_us.load();
+  if (trail_us > 0 && any_backfilled) { // compat, relaxed: see unmap_finish
+    auto own = std::make_shared<std::vector<Phys>>(std::move(lanes));
+    ctx->park(epoch, own->size() * R * ps, [ctx, pool, own, R, ps]() {
+      uint64_t ticket = 0;
+      if (options().zero_fill.load() && options().scrub_on_release.load()) {
+        std::vector<uint64_t> addrs;
+        addrs.reserve(own->size() * R);
+        for (const Phys &l : *own)
+          if (const uint64_t tag = pool->tag_of(l.h)) {
+            const uint64_t ke = pages_of(l.h), j = piece_of(l.h);
+            for (size_t r = 0; r < R; ++r) addrs.push_back(tag + ((uint64_t)r * ke + j) * ps);
+          }
+        if (!addrs.empty()) ticket = ctx->scrub(addrs.data(), addrs.size(), ps);
+      }
+      pool->release_batch(own->data(), own->size(), ticket);
+    });
+    ctx->request_async_flush(trail_us);
+    sg.mark(16);
+    stats().pages_unmapped += (int64_t)(own->size() * R);
+    return own->size();
+  }
   const bool defer = options().defer_unmap_shootdown.load() || options().async_shootdown.load();
   if (any_backfilled || !defer)
     ctx->ensure_flushed();

@@ -11,6 +11,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -42,6 +43,10 @@ struct Options {
   std::atomic<int64_t> scrub_on_release{1};      // drm backend: pages are zeroed (through an alias mapping) when they come back, not when they go out
   std::atomic<int64_t> map_shootdown_always{0};  // 1 = invalidate after every map batch even when no stale translation can exist
   std::atomic<int64_t> defer_unmap_shootdown{0}; // unmap's invalidation may wait for the next map batch / driver release
+  // compat regions: the invalidation an unmap owes may trail the call by at most `deferred_unmap_flush_us` (0 = inside the call,
+  // the default): the pages wait un-scrubbed and un-offered until it has happened, and the next map batch's own invalidation
+  // absorbs it if it comes first (KVCACHED_UNMAP_INVALIDATION_US)
+  std::atomic<int64_t> deferred_unmap_flush_us{0};
   std::atomic<int64_t> access_run_slots{1}; // max mappings one hipMemSetAccess call may span
   std::atomic<int64_t> zero_alias_fanout{256}; // unbacked slots that share one physical zero page
   std::atomic<int64_t> fill_chunk_slots{1024}; // slots made usable (one TLB shootdown + fill launches) at a time
@@ -164,7 +169,14 @@ public:
   // Have this context's own thread do ensure_flushed() right away (started on first use): the unmap path's 0.3-0.5 ms
   // KFD round trip leaves the caller's free(); whoever needs the invalidation earlier (the next map batch before
   // its first fill, a handle leaving for the driver) calls ensure_flushed() and waits for it or performs it.
-  void request_async_flush();
+  void request_async_flush(int64_t within_us = 0); // within_us > 0: at the latest that many microseconds from now, foreground calls or not
+  // ---- pages in limbo: unmapped, their invalidation still owed (KVCACHED_UNMAP_INVALIDATION_US). `finish` scrubs them and
+  // gives them back to their pool; it runs - on whatever thread completed an invalidation numbered >= epoch - strictly after
+  // that invalidation: a page is never zeroed nor on offer while a stale translation of it can exist.
+  void park(uint64_t epoch, size_t bytes, std::function<void()> finish);
+  void drain_limbo();                       // runs the finishers whose invalidation is over
+  void flush_limbo();                       // invalidates if anything is parked, then drains
+  size_t limbo_bytes() const { return limbo_bytes_.load(); }
   // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
   struct Foreground {
     GpuContext *c;
@@ -200,6 +212,15 @@ private:
   std::mutex fl_mu_;
   std::condition_variable fl_cv_;
   bool fl_stop_ = false, fl_kick_ = false;
+  int64_t fl_deadline_ns_ = 0; // (under fl_mu_) the async flush must have started by then (0: when the foreground is quiet)
+  struct Parked {
+    uint64_t epoch;
+    size_t bytes;
+    std::function<void()> finish;
+  };
+  std::mutex limbo_mu_;
+  std::deque<Parked> limbo_;
+  std::atomic<size_t> limbo_bytes_{0};
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes

@@ -205,3 +205,68 @@ def test_lanes_can_be_switched_off(lanes, monkeypatch):
     assert ops.map_to_kv_tensors([3 * PAGE])
     assert capi.get_stats()["pages_mapped"] == len(views)
     assert ops.unmap_from_kv_tensors([3 * PAGE])
+
+
+@pytest.mark.parametrize("layers", [1, 3])      # 1 layer, unified: the per-slot path with run-sized extents; 3 layers x K/V: lanes
+def test_the_unmap_side_invalidation_may_trail_the_call_but_pages_wait_for_it(lanes, monkeypatch, layers):
+    """KVCACHED_UNMAP_INVALIDATION_US=T (compat, relaxed): kvc_unmap_from_kv_tensors returns without its TLB
+    invalidation; the freed pages are parked - not zeroed, not on offer - until an invalidation that covers them has
+    happened: the library's own thread performs it within T microseconds, or the next map batch's own invalidation absorbs it
+    (ONE invalidation per free+alloc cycle instead of two). Strictly: page tables -> invalidation -> zero fill -> pool."""
+    import time
+    from kvcached_amd import capi, vmm_ops as ops
+    monkeypatch.setenv("KVCACHED_UNMAP_INVALIDATION_US", "400")
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true")
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "256")   # a second set of pages to alternate with (the default reserve is 2 GiB); without
+    #                                                         one a map call that finds the pool empty has the parked pages' invalidation
+    #                                                         done at once rather than create memory - two per cycle again
+    ops.init_kvcached(DEV, PAGE, False)
+    if layers == 1:
+        ts = ops.create_kv_tensors(64 * PAGE, 2, DEV, 1, 1, 0, True)
+        views, R = [ts[0].view(64, EPP)], 1
+    else:
+        ts = ops.create_kv_tensors(2 * 64 * PAGE, 2, DEV, layers, 2, 0, False)
+        views, R = [], 2 * layers
+        for t in ts:
+            views += [t[:64 * EPP].view(64, EPP), t[64 * EPP:].view(64, EPP)]
+    assert capi.get_option(capi.OPT_UNMAP_INVALIDATION_US) == 400 and (capi.get_option(129) > 0) == (layers > 1)
+    a, b = list(range(0, 8)), list(range(20, 28))
+    capi.reset_stats()                                                       # once: the ledger at the end counts from here
+    assert ops.map_to_kv_tensors([p * PAGE for p in a])
+    _stamp(views, a, 900)
+    capi.flush_unmaps()
+    s0, z0 = capi.get_stats(), capi.get_option(capi.OPT_PAGES_SCRUBBED)
+    # 1. a lone unmap: returns with the invalidation owed and the pages parked ...
+    t0 = time.perf_counter()
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in a])
+    took = time.perf_counter() - t0
+    st = capi.get_stats()
+    assert st["tlb_shootdowns"] == s0["tlb_shootdowns"] and capi.get_option(capi.OPT_PAGES_SCRUBBED) == z0, (st, took)
+    assert st["pages_unmapped"] - s0["pages_unmapped"] == 8 * R
+    # ... and the library's thread has it done a moment later, by itself: invalidation first, zero fill after, then the pool
+    time.sleep(0.02)
+    st = capi.get_stats()
+    assert st["tlb_shootdowns"] == s0["tlb_shootdowns"] + 1 and capi.get_option(capi.OPT_PAGES_SCRUBBED) == z0 + 8 * R
+    for v in views:
+        assert int(torch.count_nonzero(v[0:8, ::512])) == 0                 # the freed addresses read zero
+    # 2. a cycle: the map batch that follows an unmap at once absorbs its invalidation - one per cycle
+    assert ops.map_to_kv_tensors([p * PAGE for p in a])
+    _stamp(views, a, 1700)
+    capi.flush_unmaps()
+    before = capi.get_stats()["tlb_shootdowns"]
+    for rnd in range(6):
+        cur, nxt = (a, b) if rnd % 2 == 0 else (b, a)
+        assert ops.unmap_from_kv_tensors([p * PAGE for p in cur])
+        assert ops.map_to_kv_tensors([p * PAGE for p in nxt])              # pages from the pool (or parked ones, after their invalidation)
+        for v in views:
+            assert int(torch.count_nonzero(v[nxt[0]:nxt[-1] + 1])) == 0, rnd   # zero, every word: nothing of the other set's stamps
+        _stamp(views, nxt, 2000 + 100 * rnd)
+        _check(views, nxt, 2000 + 100 * rnd)
+    cycles = capi.get_stats()["tlb_shootdowns"] - before
+    assert cycles <= 6 + 2, cycles                                           # (strict compat: 12)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in (b if rnd % 2 == 0 else a)])
+    capi.flush_unmaps()
+    assert capi.get_option(124) == 0
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]

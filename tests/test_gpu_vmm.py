@@ -5,6 +5,7 @@ aliases one zero page, backed pages are private) and adds what the north star ad
 pages read as zeros even when the physical handle is recycled and dirty.
 """
 import os
+import time
 
 import pytest
 import torch
@@ -126,6 +127,8 @@ _CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("dr
              ("drm", "lazy", 0, 64, "KVCACHED_PRT=true"), ("drm", "lazy", 0, 1, "KVCACHED_PRT=true"),      # lazy with PRT (opt-in)
              ("drm", "compat", 0, 64, "KVCACHED_PRT=false"),                                              # zero extent
              ("drm", "compat", 0, 1, "KVCACHED_PRT=false")]
+# compat, relaxed: the invalidation an unmap owes trails the call by at most 300 us; the pages wait for it un-scrubbed, un-offered
+_CONFIGS += [(b, "compat", 0, ck, "KVCACHED_UNMAP_INVALIDATION_US=300") for b, ck in (("drm", 64), ("drm", 1), ("hybrid", 1), ("hip", 1))]
 
 
 @pytest.mark.parametrize("backend,mode,async_unmap,extent_pages,switch", _CONFIGS)
@@ -167,6 +170,11 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
         assert ops.unmap_from_kv_tensors([i * PAGE for i in victims])
         if capi.get_option(capi.OPT_PRT) and mode == "lazy":
             capi.flush_unmaps()                                        # lazy: the invalidation runs behind the call
+        if switch.startswith("KVCACHED_UNMAP_INVALIDATION_US"):
+            if rnd % 2:
+                time.sleep(0.003)                                      # relaxed compat: "reads as zeros" holds 300 us after the call at the latest, by itself
+            else:
+                capi.flush_unmaps()                                    # ... or at once for whoever asks
         for i in victims:
             stamp.pop(i)
             if mode == "compat" or capi.get_option(capi.OPT_PRT):      # (PRT: unbacked VA reads as zeros in lazy mode too)
