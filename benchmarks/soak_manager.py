@@ -52,12 +52,13 @@ def main():
         os.environ["KVCACHED_PHYS_CHUNK_PAGES"] = str(args.extent_pages)
     if args.touch_unbacked and not args.compat:
         os.environ["KVCACHED_PRT"] = "true"        # lazy mode leaves unbacked VA unmapped by default: touching it would fault
-    if args.touch_unbacked and (args.prealloc or args.async_unmap):
-        # A slot IN TRANSITION is not at rest: inside the one ioctl that replaces PRT by a page (or back) the kernel first
-        # clears the range and then writes the new entries, and a GPU access that lands in that window faults (found the
-        # hard way: profiles/r02_soak_touch_unbacked_fault.log). Nothing legitimate touches a slot that is being backed or
-        # given up - but this sweep would, as soon as another thread of the library maps or unmaps in the background.
-        raise SystemExit("--touch-unbacked only without --prealloc / --async-unmap: it must not race with background (un)mapping")
+    # A slot IN TRANSITION is not at rest: inside the one ioctl that replaces PRT by a page (or back) the kernel first clears
+    # the range and then writes the new entries, and a GPU access that lands in that window faults (found the hard way:
+    # profiles/r02_soak_touch_unbacked_fault.log; there is no sequence of DRM operations without the window:
+    # tools/engine_ioctl_probe.cpp part H). Nothing legitimate touches a slot that is being backed or given up - but these
+    # sweeps would, as soon as another thread of the library maps or unmaps in the background (the prealloc thread, the
+    # reclaimer). So they run under capi.quiesced() - kvc_quiesce_begin/_end, the library's own fence for code that reads
+    # whole KV tensors - which holds every page-table update for as long as a sweep's kernels run.
     if args.backend:
         os.environ["KVCACHED_VMM_BACKEND"] = args.backend
     os.environ["KVCACHED_ASYNC_UNMAP"] = "true" if args.async_unmap else "false"
@@ -165,8 +166,9 @@ def main():
             # per 4 KiB (chip-wide: every XCD's TLBs get to see the unbacked neighbours of whatever is backed - the shape that
             # tools/prt_tlb_probe.cpp needed to show what cached PRT entries do)
             stride = PAGE // 8 if (n_ops // 32) % 2 else 512
-            for w in words:
-                touched_sum += int(w[::stride].sum())
+            with capi.quiesced():                               # (no slot is in transition while the kernels run)
+                for w in words:
+                    touched_sum += int(w[::stride].sum())
             counts["sweeps_over_every_slot"] = counts.get("sweeps_over_every_slot", 0) + 1
         if n_ops % 64 == 0:
             st_now = capi.get_stats()
@@ -189,11 +191,13 @@ def main():
                 # the window that only a map opens (until the next unmap the kernel has the remainders of the PRT mappings this
                 # alloc has split still queued): the unbacked neighbours are looked at chip-wide BEFORE the new
                 # blocks are written, and the blocks are read back at once
-                for w in words:
-                    touched_sum += int(w[::512].sum())
+                with capi.quiesced():
+                    for w in words:
+                        touched_sum += int(w[::512].sum())
                 sign(ids_t, next_rid)
-                for w in words:
-                    touched_sum += int(w[::512].sum())
+                with capi.quiesced():
+                    for w in words:
+                        touched_sum += int(w[::512].sum())
                 wnow = verify(ids_t, next_rid)
                 if wnow:
                     bad += wnow

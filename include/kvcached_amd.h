@@ -136,13 +136,24 @@ int kvc_unmap_from_kv_tensors(const int64_t *offsets, size_t n, int64_t group_id
  * 110 pages straight from KFD, 111 invalidations done off the callers' threads, 112-117 page creation / release time
  * split, 118 the KFD ioctl pair is the invalidation in use, 119 pages per extent at most, 120-124 the extent pool's
  * footprint, 125/126 pages zeroed on their way back / handed out without a fill of their own, 127 pages of the zero
- * extent, 128 PRT behind unbacked VA, 130-149 host nanoseconds of the map / unmap calls by segment (bench.py). */
+ * extent, 128 PRT behind unbacked VA, 129 lanes per buffer (page ids backed as units), 130-153 host nanoseconds of the map /
+ * unmap calls by segment and ioctl counts (bench.py), 163/164 peer pages imported straight into KFD + DRM / through the runtime. */
 enum { KVC_OPT_ZERO_BACKFILL = 1, KVC_OPT_ZERO_FILL = 2, KVC_OPT_POOL_BYTES = 3, KVC_OPT_PROFILE = 4,
        KVC_OPT_TLB_SHOOTDOWN = 5, KVC_OPT_DEFER_UNMAP_SHOOTDOWN = 6, KVC_OPT_ASYNC_UNMAP = 7,
        KVC_OPT_UNMAP_INVALIDATION_US = 8 };
 int kvc_set_option(int opt, int64_t value);
 int64_t kvc_get_option(int opt);
 int kvc_flush_unmaps(void); /* wait until every queued (async) unmap has been carried out */
+/* Hold every page-table update of this process's KV regions (map / unmap calls of any thread, the prealloc thread, the
+ * reclaimer) between _begin and _end, from the thread that called _begin. For code that reads or copies WHOLE KV tensors,
+ * unbacked parts included (a checkpoint, a debugger's dump, the soak's sweeps): "unbacked VA reads as zeros, never faults"
+ * holds for slots at rest, but inside the one ioctl that backs a slot or gives it up the kernel clears the entries before
+ * it writes the new ones, and an access that lands on exactly that slot in that window (~2 us) is a GPU fault - there is no
+ * sequence of DRM operations without it (tools/engine_ioctl_probe.cpp, part H). The engine's own accesses never meet it:
+ * nothing touches a slot that is being backed (not handed out yet) or given up (already freed). No reference counterpart
+ * (its FTensor::map unmaps the zero alias and maps the page in two separate calls: csrc/ftensor.cpp:100-118). */
+int kvc_quiesce_begin(void);
+int kvc_quiesce_end(void);
 
 /* Counters since kvc_init / last reset. */
 typedef struct kvc_stats {

@@ -82,6 +82,8 @@ SIGNATURES = {
     "kvc_get_stats": (_int, [ctypes.POINTER(Stats)]),
     "kvc_reset_stats": (_int, []),
     "kvc_flush_unmaps": (_int, []),
+    "kvc_quiesce_begin": (_int, []),
+    "kvc_quiesce_end": (_int, []),
     "kvc_get_driver_breakdown": (_int, [_I64P]),
     "kvc_mem_get_info": (_int, [_SZP, _SZP]),
     "kvc_set_mem_info_override": (_int, [_sz, _sz]),
@@ -219,6 +221,20 @@ def get_driver_breakdown() -> dict:
 
 def flush_unmaps() -> None:
     check(lib.kvc_flush_unmaps())
+
+
+class quiesced:
+    """`with capi.quiesced():` - no page-table update of this process's KV regions happens inside the block (map / unmap calls of
+    other threads, the prealloc thread and the reclaimer wait): the way to read or copy WHOLE KV tensors, unbacked parts
+    included, next to background mapping (a slot in transition is not at rest: include/kvcached_amd.h, kvc_quiesce_begin)."""
+
+    def __enter__(self):
+        check(lib.kvc_quiesce_begin())
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.kvc_quiesce_end())
+        return False
 
 
 def reset_stats() -> None:

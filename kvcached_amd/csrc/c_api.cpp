@@ -251,6 +251,18 @@ int kvc_get_stats(kvc_stats_t *o) {
   o->compact_ms = s.compact_ms;
   return KVC_OK;
 }
+int kvc_quiesce_begin(void) {
+  return guarded([&]() -> int {
+    KvAllocator::quiesce_all(true);
+    return KVC_OK;
+  });
+}
+int kvc_quiesce_end(void) {
+  return guarded([&]() -> int {
+    KvAllocator::quiesce_all(false);
+    return KVC_OK;
+  });
+}
 int kvc_flush_unmaps(void) {
   return guarded([&]() -> int {
     KvAllocator::flush_all_unmaps();

@@ -619,6 +619,32 @@ void KvAllocator::flush_all_unmaps() {
   }
 }
 
+void KvAllocator::quiesce_all(bool on) {
+  static std::mutex q_mu;                                   // one holder at a time
+  static std::vector<std::unique_lock<std::mutex>> held;    // (owned by the holder's thread between begin and end)
+  static std::unique_lock<std::mutex> holder;
+  if (on) {
+    std::unique_lock<std::mutex> me(q_mu);
+    std::vector<KvAllocator *> all;
+    {
+      std::lock_guard<std::mutex> g(g_mu);
+      for (auto &kv : g_allocators) all.push_back(kv.second.get());
+    }
+    std::sort(all.begin(), all.end()); // a fixed order: two holders cannot exist, but map calls of several groups do
+    for (auto *a : all) {
+      std::unique_lock<std::mutex> lk(a->mu_, std::defer_lock);
+      a->lock_foreground(lk); // (ahead of the reclaimer)
+      held.push_back(std::move(lk));
+    }
+    holder = std::move(me);
+  } else {
+    if (!holder.owns_lock()) throw InvalidError("kvc_quiesce_end without kvc_quiesce_begin");
+    held.clear();
+    holder.unlock();
+    holder = std::unique_lock<std::mutex>();
+  }
+}
+
 size_t KvAllocator::pending_unmap_bytes() { return g_pending_unmap_bytes.load(); }
 
 std::unique_ptr<KvRegion> KvAllocator::make_region(const std::string &name, size_t size, size_t page_size) {

@@ -344,6 +344,8 @@ public:
   // been carried out; bytes still queued (they count as free for this process)
   void flush_unmaps();
   static void flush_all_unmaps();
+  // every allocator's lock, taken (true) / released (false) by the calling thread: no page-table update in between
+  static void quiesce_all(bool on);
   static size_t pending_unmap_bytes();
 
   // TP shared pool

@@ -281,6 +281,20 @@ int main() {
     printf("G runs of 8 slots per row (exact): REPLACE by 8 pages %.2f us/ioctl (%.2f us per 2 MiB), rewrite ioctl %.1f us, back to PRT %.2f us/ioctl\n",
            g_rep / (ROUNDS - 2) / R, g_rep / (ROUNDS - 2) / R / 8, g_rw / (ROUNDS - 2), g_back / (ROUNDS - 2) / R);
     fflush(stdout);
+    // ---- H: is there a way from PRT to a page WITHOUT an instant in which the entry is invalid?
+    //   REPLACE is clear-then-map inside one ioctl (amdgpu_vm_bo_replace_map: the old mapping goes to the freed list, whose
+    //   entries are written as INVALID by amdgpu_vm_clear_freed before amdgpu_vm_bo_update writes the new ones); DELAY_UPDATE
+    //   only postpones both passes to the next plain ioctl, where they still run in that order (F above: the data arrives, but
+    //   between the two passes - now 64 ranges apart instead of one - the entries are invalid for longer, not shorter).
+    //   The remaining candidate: MAP the page OVER the PRT mapping, so that the entry goes PRT -> valid in one write.
+    {
+      const int rc = amdgpu_bo_va_op_raw(dev, big.bo, 0, PAGE, at(0, 40), RWX, AMDGPU_VA_OP_MAP);
+      printf("H MAP of a page over a PRT mapping (no REPLACE): %s - mappings of one address space may not overlap, so there is no sequence without an\n"
+             "  invalid window; the window is the time between two page-table passes of ONE ioctl (~2 us per range), and nothing legitimate looks at\n"
+             "  a slot that is being backed or given up\n", rc == 0 ? "ACCEPTED (unexpected)" : strerror(rc < 0 ? -rc : rc));
+      if (rc == 0) DK(amdgpu_bo_va_op_raw(dev, nullptr, 0, PAGE, at(0, 40), AMDGPU_VM_PAGE_PRT, AMDGPU_VA_OP_REPLACE));
+      fflush(stdout);
+    }
     for (int r = 0; r < R; r++) DK(amdgpu_bo_va_op_raw(dev, nullptr, 0, (uint64_t)S * PAGE, at(r, 0), 0, AMDGPU_VA_OP_CLEAR));
     DK(amdgpu_bo_va_op_raw(dev, nullptr, 0, PAGE, (uint64_t)scratch, 0, AMDGPU_VA_OP_CLEAR));
     tlb_shootdown();

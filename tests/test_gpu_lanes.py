@@ -270,3 +270,47 @@ def test_the_unmap_side_invalidation_may_trail_the_call_but_pages_wait_for_it(la
     ops.shutdown_kvcached()
     st = capi.get_stats()
     assert st["handles_created"] == st["handles_released"]
+
+
+def test_whole_tensors_can_be_read_next_to_background_mapping(lanes, monkeypatch):
+    """"Unbacked VA reads as zeros, never faults" holds for slots at rest; a slot in transition - inside the one ioctl that backs
+    it or gives it up - has invalid entries for ~2 us, and an access that lands there is a GPU fault
+    (profiles/r02_soak_touch_unbacked_fault.log; no DRM sequence avoids it: tools/engine_ioctl_probe.cpp part H).
+    kvc_quiesce_begin/_end hold every page-table update meanwhile: a thread hammers map/unmap while this one sums EVERY word
+    of every region, backed or not, under the fence - no fault, the sums only ever show what the other thread stamped."""
+    import threading
+    import time
+    ops, capi, views = _engine(lanes, layers=2, ids_per_half=64, compat=True)
+    stop, errors, rounds = threading.Event(), [], [0]
+
+    def churn():
+        torch.cuda.set_device(0)
+        try:
+            k = 0
+            while not stop.is_set():
+                ids = [(k * 5 + j) % 64 for j in range(1 + k % 6)]
+                ids = sorted(set(ids))
+                assert ops.map_to_kv_tensors([p * PAGE for p in ids])
+                assert ops.unmap_from_kv_tensors([p * PAGE for p in ids])
+                k += 1
+                rounds[0] = k
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=churn)
+    t.start()
+    try:
+        t0, sweeps = time.time(), 0
+        while time.time() - t0 < 6:
+            with capi.quiesced():
+                total = sum(int(v[:, ::256].to(torch.int64).sum()) for v in views)   # a word of every 512 B of every slot
+            assert total == 0                                                       # nobody stamps anything here: zeros everywhere
+            sweeps += 1
+            time.sleep(0.002)                                                       # (the fence is a plain mutex: give the other thread its turn)
+    finally:
+        stop.set()
+        t.join(30)
+    assert not errors, errors
+    assert sweeps > 20 and rounds[0] > 100, (sweeps, rounds)
+    with pytest.raises(RuntimeError):
+        capi.check(capi.lib.kvc_quiesce_end())                                     # an end without a begin is refused

@@ -4,7 +4,7 @@
 # usage: ./tools_gpu_round.sh <stage: 1|2|tests> [round tag, default r02]
 set -o pipefail
 export TMPDIR=/tmp
-STAGE=${1:-1}; R=${2:-r02}
+STAGE=${1:-1}; R=${2:-r03}
 mkdir -p gpurun_out
 if [ "$STAGE" = "1" ] || [ "$STAGE" = "tests" ]; then
   echo "== pytest -m gpu"
@@ -32,7 +32,7 @@ fi
 if [ "$STAGE" = "2" ]; then
   echo "== soak: default pool, then pool off (fragmentation alone), then prealloc + watcher + resizes, then one buffer per page"
   : > gpurun_out/${R}_soak.jsonl
-  for args in "--seconds 60 --compat --touch-unbacked" "--seconds 60 --touch-unbacked" "--seconds 45 --compat --prealloc" "--seconds 60" "--seconds 60 --pool-mb 0" "--seconds 60 --prealloc" "--seconds 45 --pool-mb 0 --extent-pages 32" "--seconds 45 --pool-mb 0 --extent-pages 1" "--seconds 30 --extent-pages 1" "--seconds 45 --compat" "--seconds 45 --async-unmap --prealloc" "--seconds 30 --compat --touch-unbacked --no-prt" "--seconds 30 --compat --touch-unbacked --backend hybrid"; do
+  for args in "--seconds 60 --compat --touch-unbacked" "--seconds 60 --touch-unbacked" "--seconds 45 --compat --prealloc --touch-unbacked" "--seconds 45 --compat --touch-unbacked --unmap-invalidation-us 300" "--seconds 60" "--seconds 60 --pool-mb 0" "--seconds 60 --prealloc" "--seconds 45 --pool-mb 0 --extent-pages 32" "--seconds 45 --pool-mb 0 --extent-pages 1" "--seconds 30 --extent-pages 1" "--seconds 45 --compat" "--seconds 45 --async-unmap --prealloc" "--seconds 30 --compat --touch-unbacked --no-prt" "--seconds 30 --compat --touch-unbacked --backend hybrid"; do
     timeout -k 10 200 python benchmarks/soak_manager.py $args 2> gpurun_out/soak.err | tail -1 >> gpurun_out/${R}_soak.jsonl; rc=$?
     tail -1 gpurun_out/${R}_soak.jsonl | cut -c1-700; echo "soak ($args) rc=$rc"
     [ $rc -ne 0 ] && { grep -v amdgpu.ids gpurun_out/soak.err | tail -20; exit $rc; }
