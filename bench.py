@@ -266,32 +266,57 @@ def roofline_from(st):
 
 def compaction_roofline(capi, device):
     """Secondary kernel: compact_blocks on the Llama-3-8B geometry (64 regions = 32 layers x K/V, 32 KiB blocks,
-    2048 disjoint moves = 4 GiB read + 4 GiB written). Event-timed like zero_fill_pages."""
+    2048 disjoint moves = 4 GiB read + 4 GiB written). Event-timed like zero_fill_pages. Next to it, in the same session, the
+    CEILING of a copy on this box: the same kernel on ONE region with 2 MiB blocks i -> i + 1024, i.e. a contiguous
+    2 GiB -> 2 GiB copy (what scattering 32 KiB blocks over 64 regions costs is the difference), and torch's own D2D copy."""
     import numpy as np
     import torch
+
+    def timed(bases, src, dst, block, reps=5):
+        for _ in range(2):
+            capi.compact_blocks(bases, src, dst, block)
+        capi.set_option(capi.OPT_PROFILE, 1)
+        capi.reset_stats()
+        for _ in range(reps):
+            capi.compact_blocks(bases, src, dst, block, sync=False)
+        capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
+        st = capi.get_stats()
+        capi.set_option(capi.OPT_PROFILE, 0)
+        return st
+
     block, regions, n_blocks, moves = 32 * 1024, 64, 4096, 2048
     capi.init(device, PAGE, False)
     try:
         bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device=device) for _ in range(regions)]
         ids = np.random.default_rng(0).permutation(n_blocks)[:2 * moves]
         src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
-        bases = [b.data_ptr() for b in bufs]
         torch.cuda.synchronize()
-        for _ in range(2):
-            capi.compact_blocks(bases, src, dst, block)
-        capi.set_option(capi.OPT_PROFILE, 1)
-        capi.reset_stats()
-        for _ in range(5):
-            capi.compact_blocks(bases, src, dst, block, sync=False)
-        capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
-        st = capi.get_stats()
-        capi.set_option(capi.OPT_PROFILE, 0)
+        st = timed([b.data_ptr() for b in bufs], src, dst, block)
         achieved = st["compact_bytes"] / (st["compact_ms"] * 1e-3) / 1e9
-        return {"kernel": "compact_blocks (LDS-staged, XCD-aware, non-temporal)", "bound": "hbm", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
-                "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],
-                "avg_launch_us": round(st["compact_ms"] / st["compact_launches"] * 1e3, 2)}
+        out = {"kernel": "compact_blocks (LDS-staged, XCD-aware, non-temporal, 32 KiB tiles)", "bound": "hbm", "achieved": round(achieved, 1),
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+               "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
+               "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],
+               "avg_launch_us": round(st["compact_ms"] / st["compact_launches"] * 1e3, 2)}
+        del bufs
+        big = torch.randint(0, 127, (4 * GiB,), dtype=torch.int8, device=device)
+        torch.cuda.synchronize()
+        stc = timed([big.data_ptr()], list(range(1024)), list(range(1024, 2048)), 2 * MiB)
+        ceiling = stc["compact_bytes"] / (stc["compact_ms"] * 1e-3) / 1e9
+        a, b = big[:2 * GiB], big[2 * GiB:]
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        out["copy_ceiling_GBps"] = round(ceiling, 1)
+        out["copy_ceiling"] = ("the same kernel, same session, on ONE region with 2 MiB blocks i -> i + 1024: a contiguous 2 GiB -> 2 GiB copy, "
+                               "read + written bytes over event time")
+        out["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+        out["torch_d2d_copy_GBps"] = round(5 * 2 * 2 * GiB / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        return out
     finally:
         capi.shutdown()
 

@@ -14,8 +14,9 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KiB = 1 << 10
-VARIANTS = ["lds+xcd+nt (default)", "reg+xcd+nt", "lds", "reg", "lds+xcd", "reg+xcd"]
-GEOMETRIES = ((32 * KiB, 64, 4096, 2048),     # Llama-3-8B: 32 layers x K/V regions, 32 KiB blocks
+VARIANTS = ["default (= lds+xcd+nt, 32 KiB tiles)", "reg+xcd+nt", "lds", "reg", "lds+xcd", "reg+xcd", "lds+xcd+nt, 32 KiB tiles", "reg+xcd+nt, 32 KiB tiles", "lds+xcd+nt, 16 KiB tiles (default until r03)"]
+GEOMETRIES = ((2048 * KiB, 1, 2048, 1024),    # the ceiling: ONE region, 2 MiB blocks i -> i + 1024, i.e. a contiguous 2 GiB -> 2 GiB copy through the same kernel
+              (32 * KiB, 64, 4096, 2048),     # Llama-3-8B: 32 layers x K/V regions, 32 KiB blocks
               (32 * KiB, 64, 4096, 256),
               (16 * KiB, 32, 8192, 2048),     # cfg 1 of the reference's tests: 16 layers, 16 KiB blocks
               (18432, 54, 4096, 1024))        # MLA-like: 16 tokens x 1152 B, 27 layers x 2
@@ -27,6 +28,8 @@ def setup(block, regions, n_blocks, moves):
     bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device="cuda:0") for _ in range(regions)]
     ids = np.random.default_rng(0).permutation(n_blocks)[:2 * moves]
     src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
+    if regions == 1:                             # the contiguous case
+        src, dst = list(range(moves)), list(range(moves, 2 * moves))
     torch.cuda.synchronize()
     return bufs, [b.data_ptr() for b in bufs], src, dst
 
@@ -43,7 +46,7 @@ def main():
     capi.init("cuda:0", 2 << 20, False)
     try:
         if args.profile_shape:
-            block, regions, n_blocks, moves = GEOMETRIES[0]
+            block, regions, n_blocks, moves = GEOMETRIES[1]
             bufs, bases, src, dst = setup(block, regions, n_blocks, moves)
             for _ in range(6):
                 capi.compact_blocks(bases, src, dst, block)

@@ -118,6 +118,9 @@ static constexpr int kCompactThreads = 256;          // 4 waves
 static constexpr int kCompactTile = 16 * 1024;       // bytes per workgroup: 4 waves x 4 x 1 KiB
 static constexpr int kPiece = 1024;                  // one wave-instruction
 static constexpr int kPiecesPerWave = kCompactTile / kPiece / (kCompactThreads / 64);
+// variants 6 / 7 (A/B): twice the bytes in flight per wave - 32 KiB per workgroup, 8 pieces per wave
+static constexpr int kCompactTileBig = 32 * 1024;
+static constexpr int kPiecesPerWaveBig = kCompactTileBig / kPiece / (kCompactThreads / 64);
 
 // blockIdx -> (region, move, tile). XCD == true: the (region, move) pairs are dealt to the 8 XCDs so that one
 // XCD copies a whole block (all its tiles) — the same placement idea as zero_fill_pages; speed only.
@@ -226,6 +229,59 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(Com
   }
 }
 
+// Variants 6 (LDS-staged) and 7 (register-staged) with 32 KiB tiles: every wave has 8 KiB in flight instead of 4.
+template <bool LDS>
+__global__ __launch_bounds__(kCompactThreads) void compact_blocks_big_kernel(CompactArgs a, unsigned n_moves, unsigned n_regions,
+                                                                              unsigned tiles_per_block, unsigned block_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[LDS ? kCompactTileBig : 16];
+  const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+  const unsigned q = i / tiles_per_block, t = i - q * tiles_per_block, pair = q * 8u + x;
+  if (pair >= n_moves * n_regions) return;
+  const unsigned r = pair / n_moves, m = pair - r * n_moves;
+  const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTileBig;
+  char *dst = static_cast<char *>(a.base[r]) + a.dst[m] * (int64_t)block_bytes + (size_t)t * kCompactTileBig;
+  const unsigned remain = block_bytes - t * kCompactTileBig;
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool full = remain >= (unsigned)kCompactTileBig;
+  const unsigned limit = full ? (unsigned)kCompactTileBig : remain;
+  if (LDS) {
+#pragma unroll
+    for (int k = 0; k < kPiecesPerWaveBig; ++k) {
+      const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+      if (full || off < limit)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                         (__attribute__((address_space(3))) void *)(tile + (wave * kPiecesPerWaveBig + k) * kPiece), 16, 0, 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (full) {
+      v4u v[kPiecesPerWaveBig];
+#pragma unroll
+      for (int k = 0; k < kPiecesPerWaveBig; ++k) v[k] = *reinterpret_cast<const v4u *>(tile + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16);
+#pragma unroll
+      for (int k = 0; k < kPiecesPerWaveBig; ++k)
+        __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+    } else {
+      for (int k = 0; k < kPiecesPerWaveBig; ++k) {
+        const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+        if (off < limit) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(tile + off);
+      }
+    }
+  } else if (full) {
+    v4u v[kPiecesPerWaveBig];
+#pragma unroll
+    for (int k = 0; k < kPiecesPerWaveBig; ++k)
+      v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+#pragma unroll
+    for (int k = 0; k < kPiecesPerWaveBig; ++k)
+      __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+  } else {
+    for (int k = 0; k < kPiecesPerWaveBig; ++k) {
+      const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+      if (off < limit) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(src + off);
+    }
+  }
+}
+
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant) {
   if (n_regions <= 0 || n_moves <= 0) return hipSuccess;
@@ -251,6 +307,19 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
   // Non-temporal loads and stores are the default: every byte is touched exactly once, and keeping it out of the
   // way of the L2/MALL is worth +2..7 % (profiles/r01_compact_bench.jsonl; same on a plain contiguous copy,
   // tools/copy_bench.cpp: 5.9 vs 5.66 TB/s).
+  // Default since round 3: LDS-staged, XCD-aware, non-temporal, 32 KiB tiles (8 KiB in flight per wave): the same rate as the
+  // 16 KiB tiles on 32 KiB blocks (5.47 vs 5.50 TB/s), +2.6 % on 16 KiB blocks and +12 % on ragged 18 KiB MLA blocks (one tile per
+  // block instead of a full one and a 2 KiB tail) - profiles/r03_compact_bench.jsonl. Variant 8 is the 16 KiB-tile form.
+  if (variant == 0) variant = 6;
+  if (variant == 6 || variant == 7) {
+    const unsigned tiles_big = (unsigned)((block_bytes + kCompactTileBig - 1) / kCompactTileBig);
+    const size_t g = (size_t)tiles_big * ((pairs + 7) / 8 * 8);
+    if (variant == 6)
+      compact_blocks_big_kernel<true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
+    else
+      compact_blocks_big_kernel<false><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
+    return hipGetLastError();
+  }
   switch (variant) {
   case 1: // register-staged, XCD-aware, non-temporal
     compact_blocks_reg_kernel<true, true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
@@ -267,7 +336,7 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
   case 5: // register-staged, XCD-aware, temporal
     compact_blocks_reg_kernel<true, false><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
     break;
-  default: // LDS-staged, XCD-aware, non-temporal
+  default: // (8) LDS-staged, XCD-aware, non-temporal, 16 KiB tiles: the default until round 3
     compact_blocks_lds_kernel<true, true><<<dim3((unsigned)grid_xcd), blk, 0, stream>>>(a, nm, nr, tiles, bb);
   }
   return hipGetLastError();

@@ -370,6 +370,48 @@ def gen_prefix_cache():
     dump("prefix_cache.json", {"meta": META, "cache_keys": keys, "cases": cases})
 
 
+def gen_prefix_cache_real_manager():
+    """The same request traces through the reference's ElasticBlockPool over the reference's REAL KVCacheManager (on its cpu
+    device, like the manager traces above; the free-memory reading is the _RefPA input, far above what the traces need): block
+    ids, free counts, cached keys and the eviction order now include what a page-granular manager does below the pool
+    (VERDICT r02 #6). The product is compared with this recording op for op, on its cpu device and on cuda:0."""
+    import types
+    import kvcached.integration.vllm.interfaces as ref_vi
+    from kvcached.integration.vllm.patches import ElasticBlockPoolPatch
+    g = T.PREFIX_REAL_GEOMETRY
+    block_bytes = g["block_tokens"] * g["cell"]
+    cases = []
+    for c in kvc_traces.PREFIX_CACHE_CASES:
+        if c["name"] not in ("default_cap_1000", "cap_5", "tiny_pool_pressure"):
+            continue
+        n = c["num_blocks"]
+        pages = -(-n * block_bytes // PAGE)
+        ref_kcm.CONTIGUOUS_LAYOUT = False
+        ref_ops.init_kvcached("cpu", PAGE, False)
+        _RefPA.phys_pages = 1 << 40
+        ref_vi._kvcached_initialized, ref_vi._world_size, ref_vi._pp_rank, ref_vi._async_sched = True, 1, 0, False
+        ref_vi._is_worker = True      # (worker and scheduler in one process, as with TP=1: pages are mapped locally, vllm/interfaces.py:29-30,42-48)
+        try:
+            ref_ops.create_kv_tensors(pages * PAGE * 2, 1, "cpu", g["layers"], 2, 0, False)
+            mod = types.ModuleType("fake_block_pool")
+            mod.BlockPool, mod.KVCacheBlock = T.FakeBlockPool, T.FakeKVCacheBlock
+            ElasticBlockPoolPatch().inject_elastic_block_pool(mod)
+            pool = mod.ElasticBlockPool(num_gpu_blocks=n, block_size=g["block_tokens"], cell_size=g["cell"], num_layers=g["layers"],
+                                        enable_caching=c["enable_caching"], max_cached_blocks=c["max_cached_blocks"])
+            assert isinstance(pool.kv_cache_manager, ref_kcm.KVCacheManager)          # the real one, not a stand-in
+            assert pool.kv_cache_manager._post_init_done.wait(20)
+            ops = kvc_traces.prefix_cache_ops(c["n_ops"], c["seed"], n)
+            recs = T.replay_prefix_over_real_manager(pool, ops)
+            pa = pool.kv_cache_manager.page_allocator
+            cases.append({"config": c, "geometry": g, "null_block": pool.null_block.block_id, "ops": ops, "records": recs,
+                          "pages_at_end": [pa.get_num_inuse_pages(), pa.get_num_reserved_pages(), pa.get_num_free_pages()]})
+            del pool
+        finally:
+            ref_vi._kvcached_initialized = ref_vi._is_worker = False
+            ref_ops.shutdown_kvcached()
+    dump("prefix_cache_real_manager.json", {"meta": META, "cases": cases})
+
+
 # ------------------------------------------------------------------ 8. get_avail_physical_pages on fed readings
 _AVAIL_CHILD = r"""
 import importlib.machinery, importlib.util, json, os, sys
@@ -431,5 +473,6 @@ if __name__ == "__main__":
     gen_manager()
     gen_layouts()
     gen_prefix_cache()
+    gen_prefix_cache_real_manager()
     gen_avail_physical()
     print(f"done in {time.time() - t0:.1f}s")

@@ -485,3 +485,56 @@ def replay_prefix_cache(pool, manager, ops):
                                   len(getattr(pool, "_cached_blocks", {})), h64(manager.free_ids),
                                   [b.ref_cnt for bl in live.values() for b in bl][:16]]})
     return out
+
+
+# geometry of the prefix-cache traces over a REAL manager (tests/golden/prefix_cache_real_manager.json): 256 KiB blocks, 8 per page
+PREFIX_REAL_GEOMETRY = dict(layers=2, block_tokens=16, cell=16384)
+
+
+def replay_prefix_over_real_manager(pool, ops, on_hit=None, on_new=None, after_req=None):
+    """The request trace of replay_prefix_cache through an ElasticBlockPool that sits on a REAL KVCacheManager (the reference's in
+    oracle/gen_golden.py, the product's in the tests - on its cpu device and on cuda:0). One record per op:
+    [hits + block ids | error | reset result | stat, free blocks, cached keys, evictable ids in LRU order].
+    on_hit(hash ids, blocks) / on_new(hash ids, blocks): where a GPU run checks / writes the blocks' contents."""
+    live, out = {}, []
+    for op in ops:
+        r = None
+        if op[0] == "req":
+            _, rid, hashes, group = op
+            hs = [b"h%06d" % h for h in hashes]
+            hit_blocks = []
+            for h in hs:
+                got = pool.get_cached_block(h, [group])
+                if not got:
+                    break
+                hit_blocks.append(got[0])
+            if hit_blocks:
+                pool.touch(hit_blocks)
+                if on_hit:
+                    on_hit(hashes[:len(hit_blocks)], hit_blocks)
+            need = len(hs) - len(hit_blocks)
+            try:
+                new = pool.get_new_blocks(need) if need else []
+            except ValueError as e:
+                r = "ValueError: " + str(e)
+            else:
+                if on_new:
+                    on_new(hashes[len(hit_blocks):], new)
+                blocks = hit_blocks + new
+                pool.cache_full_blocks(FakeRequest(hs), blocks, len(hit_blocks), len(blocks), 16, group)
+                live[rid] = blocks
+                r = {"hit": len(hit_blocks), "ids": [b.block_id for b in blocks]}
+                if after_req:
+                    after_req()
+        elif op[0] == "fin":
+            pool.free_blocks(reversed(live.pop(op[1], [])))
+        elif op[0] == "evict":
+            pool.evict_blocks(set(op[1]))
+        elif op[0] == "reset":
+            r = pool.reset_prefix_cache()
+        elif op[0] == "stat":
+            r = [pool.get_num_free_blocks(), len(pool.take_events())]
+        out.append([r, pool.get_num_free_blocks(), len(pool._cached_blocks), list(pool._evictable_blocks.keys())])
+    for blocks in live.values():
+        pool.free_blocks(reversed(blocks))
+    return out

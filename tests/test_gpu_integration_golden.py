@@ -17,7 +17,7 @@ import kvc_testlib as T
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LAYOUTS = json.load(open(os.path.join(T.GOLDEN_DIR, "alloc_kv_cache_layouts.json")))["cases"]
-PREFIX = json.load(open(os.path.join(T.GOLDEN_DIR, "prefix_cache.json")))
+PREFIX_REAL = json.load(open(os.path.join(T.GOLDEN_DIR, "prefix_cache_real_manager.json")))
 
 
 class _Props:
@@ -115,14 +115,15 @@ def _blk_view(tensors, block_id, block_bytes):
 
 
 def _run_prefix_trace(monkeypatch, case, device):
-    """The reference's recorded request trace through ElasticBlockPool over a real KVCacheManager on `device`. On the GPU
-    every new block is signed in device memory and every hit is checked against the signature of its hash. Returns one
-    record per op: (hits | error, block ids, free blocks, cached keys, evictable ids)."""
+    """The recorded request trace through ElasticBlockPool over a real KVCacheManager on `device`. On the GPU every new block is
+    signed in device memory and every hit is checked against the signature of its hash. Returns one record per op:
+    [hits + block ids | error, free blocks, cached keys, evictable ids] (kvc_testlib.replay_prefix_over_real_manager)."""
     cfg = case["config"]
     import kvcached_amd.integration.vllm.interfaces as vi
     from kvcached_amd import capi, vmm_ops
     from kvcached_amd.integration.vllm.block_pool import build_elastic_block_pool
-    layers, block_tokens, cell = 2, 16, 16384                               # 256 KiB blocks: 8 per 2 MiB page
+    g = case["geometry"]
+    layers, block_tokens, cell = g["layers"], g["block_tokens"], g["cell"]     # 256 KiB blocks: 8 per 2 MiB page
     block_bytes = block_tokens * cell
     n = cfg["num_blocks"]
     pages = -(-n * block_bytes // T.PAGE)
@@ -132,7 +133,6 @@ def _run_prefix_trace(monkeypatch, case, device):
         T.set_product_phys_pages(1 << 30, T.PAGE, layers, 2)
     monkeypatch.setattr(vi, "_kvcached_initialized", True)
     monkeypatch.setattr(vi, "_is_worker", True)
-    out = []
     try:
         raw = vmm_ops.create_kv_tensors(pages * T.PAGE * 2, 1, device, layers, 2, 0, False)
         cls = build_elastic_block_pool(T.FakeBlockPool, T.FakeKVCacheBlock)
@@ -140,79 +140,49 @@ def _run_prefix_trace(monkeypatch, case, device):
                    enable_caching=cfg["enable_caching"], max_cached_blocks=cfg["max_cached_blocks"])
         assert pool.kv_cache_manager._post_init_done.wait(20)
         assert pool.null_block.block_id == case["null_block"]
-        live, mapped_peak = {}, 0
-        for op in case["ops"]:
-            r = None
-            if op[0] == "req":
-                _, rid, hashes, group = op
-                hs = [b"h%06d" % h for h in hashes]
-                hit_blocks = []
-                for h in hs:
-                    got = pool.get_cached_block(h, [group])
-                    if not got:
-                        break
-                    hit_blocks.append(got[0])
-                if hit_blocks:
-                    pool.touch(hit_blocks)
-                    if on_gpu:   # the point of the test: a hit hands back a block whose CONTENT is what was written for that hash
-                        for h_id, b in zip(hashes, hit_blocks):
-                            for v in _blk_view(raw, b.block_id, block_bytes):
-                                assert int(v[0]) == h_id and int(v[-1]) == ~h_id, (rid, h_id, b.block_id)
-                need = len(hs) - len(hit_blocks)
-                try:
-                    new = pool.get_new_blocks(need) if need else []
-                except ValueError as e:
-                    r = "ValueError: " + str(e)
-                else:
-                    if on_gpu:   # "compute" the new blocks: sign them
-                        for h_id, b in zip(hashes[len(hit_blocks):], new):
-                            for v in _blk_view(raw, b.block_id, block_bytes):
-                                v[0] = h_id
-                                v[-1] = ~h_id
-                    blocks = hit_blocks + new
-                    pool.cache_full_blocks(T.FakeRequest(hs), blocks, len(hit_blocks), len(blocks), 16, group)
-                    live[rid] = blocks
-                    r = {"hit": len(hit_blocks), "ids": [b.block_id for b in blocks]}
-                    if on_gpu:
-                        st = capi.get_stats()
-                        mapped_peak = max(mapped_peak, st["pages_mapped"] - st["pages_unmapped"])
-            elif op[0] == "fin":
-                pool.free_blocks(reversed(live.pop(op[1], [])))
-            elif op[0] == "evict":
-                pool.evict_blocks(set(op[1]))
-            elif op[0] == "reset":
-                r = pool.reset_prefix_cache()
-            elif op[0] == "stat":
-                r = [pool.get_num_free_blocks(), len(pool.take_events())]
-            out.append([r, pool.get_num_free_blocks(), len(pool._cached_blocks), list(pool._evictable_blocks.keys())])
+        peak = [0]
+
+        def on_hit(hash_ids, blocks):   # the point of the GPU run: a hit hands back a block whose CONTENT is what was written for that hash
+            for h_id, b in zip(hash_ids, blocks):
+                for v in _blk_view(raw, b.block_id, block_bytes):
+                    assert int(v[0]) == h_id and int(v[-1]) == ~h_id, (h_id, b.block_id)
+
+        def on_new(hash_ids, blocks):   # "compute" the new blocks: sign them
+            for h_id, b in zip(hash_ids, blocks):
+                for v in _blk_view(raw, b.block_id, block_bytes):
+                    v[0] = h_id
+                    v[-1] = ~h_id
+
+        def after_req():
+            st = capi.get_stats()
+            peak[0] = max(peak[0], st["pages_mapped"] - st["pages_unmapped"])
+
+        out = T.replay_prefix_over_real_manager(pool, case["ops"], on_hit if on_gpu else None, on_new if on_gpu else None,
+                                                after_req if on_gpu else None)
+        pa = pool.kv_cache_manager.page_allocator
+        ends = [pa.get_num_inuse_pages(), pa.get_num_reserved_pages(), pa.get_num_free_pages()]
         if on_gpu:
             torch.cuda.synchronize()
-            assert mapped_peak > 0
-        for blocks in live.values():
-            pool.free_blocks(reversed(blocks))
+            assert peak[0] > 0
         del pool
     finally:
         vmm_ops.shutdown_kvcached()
         capi.set_mem_info_override(0, 0)
-    return out
+    return out, ends
 
 
 @pytest.mark.parametrize("name", ["default_cap_1000", "cap_5", "tiny_pool_pressure"])
 def test_prefix_cache_trace_over_a_gpu_backed_manager(monkeypatch, name):
-    """Chain of evidence for f1: the pool's logic equals the reference's on these very traces (tests/
-    test_prefix_cache_golden.py, against the recording, with the recording's stand-in manager); here the same traces run
-    over the REAL manager - once on the library's cpu device, once on cuda:0 with every map executed - and must agree op
-    for op (hits, block ids, free blocks, cached keys, eviction order), while on the GPU every hit finds its block's
-    contents intact."""
-    case = next(c for c in PREFIX["cases"] if c["config"]["name"] == name)
-    on_cpu = _run_prefix_trace(monkeypatch, case, "cpu")
-    on_gpu = _run_prefix_trace(monkeypatch, case, DEV)
-    assert len(on_cpu) == len(on_gpu) == len(case["ops"])
-    for i, (a, b) in enumerate(zip(on_cpu, on_gpu)):
-        assert a == b, f"op {i} {case['ops'][i]}: cpu device {a} != gpu {b}"
-    hits = sum(r[0]["hit"] for r in on_gpu if isinstance(r[0], dict))
-    want_hits = sum(r["r"]["hit"] for r in case["records"] if isinstance(r["r"], dict))
-    assert hits > 0 and want_hits > 0
-    if name != "tiny_pool_pressure":   # (under pressure the real manager's page-granular capacity evicts differently from the recording's)
-        golden_hit_ops = [r["r"]["hit"] for r in case["records"] if isinstance(r["r"], dict)][:40]
-        assert [r[0]["hit"] for r in on_gpu if isinstance(r[0], dict)][:40] == golden_hit_ops
+    """f1 on the GPU against the reference itself: tests/golden/prefix_cache_real_manager.json is what the
+    reference's ElasticBlockPool (kvcached/integration/vllm/patches.py:308-614) did on these request traces over its OWN
+    KVCacheManager (oracle/gen_golden.py: gen_prefix_cache_real_manager). The product's pool over the product's manager on
+    cuda:0, every map executed, must give the same record for EVERY op - hits, block ids, free blocks, cached keys, the order
+    of the evictable set, the errors of an exhausted pool - and the same page counts at the end; and what only a GPU can
+    show: every hit finds its block's contents intact in device memory."""
+    case = next(c for c in PREFIX_REAL["cases"] if c["config"]["name"] == name)
+    got, ends = _run_prefix_trace(monkeypatch, case, DEV)
+    assert len(got) == len(case["records"]) == len(case["ops"])
+    for i, (g, want) in enumerate(zip(got, case["records"])):
+        assert g == want, f"op {i} {case['ops'][i]}: cuda:0 {g} != reference {want}"
+    assert ends == case["pages_at_end"]
+    assert sum(r[0]["hit"] for r in got if isinstance(r[0], dict)) > 0

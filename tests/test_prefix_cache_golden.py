@@ -114,6 +114,45 @@ def test_pool_over_the_real_manager(monkeypatch):
         capi.set_mem_info_override(0, 0)
 
 
+REAL = json.load(open(os.path.join(T.GOLDEN_DIR, "prefix_cache_real_manager.json")))
+
+
+@pytest.mark.parametrize("idx", range(len(REAL["cases"])))
+def test_trace_over_the_real_manager_matches_the_reference(monkeypatch, idx):
+    """The reference's ElasticBlockPool over the reference's OWN KVCacheManager (oracle/gen_golden.py:
+    gen_prefix_cache_real_manager) against the product's pool over the product's manager, on the cpu device of each: every op
+    gives the same record - block ids now come from a page-granular manager, not from the stand-in of the traces above.
+    (tests/test_gpu_integration_golden.py runs the same comparison on cuda:0.)"""
+    import kvcached_amd.integration.vllm.interfaces as vi
+    from kvcached_amd import capi, vmm_ops
+    from kvcached_amd.integration.vllm.block_pool import build_elastic_block_pool
+    case = REAL["cases"][idx]
+    cfg, g = case["config"], case["geometry"]
+    assert g == T.PREFIX_REAL_GEOMETRY and kvc_traces.prefix_cache_ops(cfg["n_ops"], cfg["seed"], cfg["num_blocks"]) == case["ops"]
+    block_bytes = g["block_tokens"] * g["cell"]
+    pages = -(-cfg["num_blocks"] * block_bytes // T.PAGE)
+    vmm_ops.init_kvcached("cpu", T.PAGE, False)
+    T.set_product_phys_pages(1 << 30, T.PAGE, g["layers"], 2)
+    monkeypatch.setattr(vi, "_kvcached_initialized", True)
+    monkeypatch.setattr(vi, "_is_worker", True)
+    try:
+        vmm_ops.create_kv_tensors(pages * T.PAGE * 2, 1, "cpu", g["layers"], 2, 0, False)
+        cls = build_elastic_block_pool(T.FakeBlockPool, T.FakeKVCacheBlock)
+        pool = cls(num_gpu_blocks=cfg["num_blocks"], block_size=g["block_tokens"], cell_size=g["cell"], num_layers=g["layers"],
+                   enable_caching=cfg["enable_caching"], max_cached_blocks=cfg["max_cached_blocks"])
+        assert pool.kv_cache_manager._post_init_done.wait(20)
+        assert pool.null_block.block_id == case["null_block"]
+        got = T.replay_prefix_over_real_manager(pool, case["ops"])
+        for i, (a, want) in enumerate(zip(got, case["records"])):
+            assert a == want, f"{cfg['name']} op {i} {case['ops'][i]}: {a} != {want}"
+        pa = pool.kv_cache_manager.page_allocator
+        assert [pa.get_num_inuse_pages(), pa.get_num_reserved_pages(), pa.get_num_free_pages()] == case["pages_at_end"]
+        del pool
+    finally:
+        vmm_ops.shutdown_kvcached()
+        capi.set_mem_info_override(0, 0)
+
+
 # ---- make_cache_key: the reference's tests/test_make_cache_key.py restated against our function
 def _gid(group_id: int) -> bytes:
     return group_id.to_bytes(4, "big", signed=False)
