@@ -2,6 +2,8 @@
 # Host-side sanitizer passes over the library (GPU ASAN/XNACK are not available on the pool: CPU build only).
 # Builds libkvcached_amd.so with -Xarch_host -fsanitize=<address|thread>, swaps it in for the in-tree library,
 # runs the CPU test suite under the matching runtime, and restores the normal build.
+# (The tests' hooks build, kvcached_amd/_testhooks/, is loaded only by children of GPU tests and is left alone; the time stamp
+# of the swapped library is kept older than vmm_ops' so that tests/conftest.py does not rebuild it in the middle of the run.)
 # usage: ./tools_sanitize_cpu.sh address|thread
 set -e
 SAN=${1:-address}
