@@ -580,9 +580,17 @@ def shared_pool_in_children(rank, world):
     """Every rank of the N > 1 run starts ONE child that takes its place in the leg (own rendezvous port, own IPC name, the
     same GPU): whatever happens there - the cross-GPU import has never run on this code before an 8-GPU node sees it - the
     parent's measurement and its JSON line are safe. Rank 0 returns the leg's summary (or the error)."""
+    import socket
+    import torch.distributed as dist
     env = dict(os.environ)
-    port = int(env.get("MASTER_PORT", "29500"))
-    env["MASTER_PORT"] = str(port + 1 if port < 65000 else port - 1)
+    box = [None]
+    if rank == 0:                                                # a port that is free right now, agreed on through the parents' own group
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            box[0] = s.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    port = int(box[0])
+    env["MASTER_PORT"] = str(port)
     env["KVCACHED_IPC_NAME"] = f"kvc_bench_share_{port}"      # the same on every rank: the fd sockets live under one directory
     env.pop("KVC_BENCH_TEST_FAIL_RANK", None)
     try:

@@ -31,12 +31,15 @@ def lanes():
     capi.set_option(capi.OPT_ZERO_BACKFILL, 1)
 
 
-def _engine(state, layers, ids_per_half, compat, lane_mb=None):
+def _engine(state, layers, ids_per_half, compat, lane_mb=None, unified=False):
     ops, capi = state["ops"], state["capi"]
     os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if compat else "false"
     if lane_mb is not None:
         os.environ["KVCACHED_LANE_EXTENT_MB"] = str(lane_mb)
     ops.init_kvcached(DEV, PAGE, False)
+    if unified:                                    # one slot per layer per page id (MLA / unified pool: csrc/allocator.cpp:176-187)
+        ts = ops.create_kv_tensors(ids_per_half * PAGE, 2, DEV, layers, 1, 0, True)
+        return ops, capi, [t.view(ids_per_half, EPP) for t in ts]
     ts = ops.create_kv_tensors(2 * ids_per_half * PAGE, 2, DEV, layers, 2, 0, False)
     views = []
     for t in ts:                                   # row order = the order map_to_kv_tensors walks: layer-major, K then V
@@ -59,9 +62,9 @@ def _check(views, ids, base):
             assert bool((v[p][::4096] == want).all()), (r, p)
 
 
-@pytest.mark.parametrize("compat", [True, False])
-def test_page_ids_are_backed_and_given_back_as_units(lanes, compat):
-    ops, capi, views = _engine(lanes, layers=4, ids_per_half=64, compat=compat)
+@pytest.mark.parametrize("compat,unified", [(True, False), (False, False), (True, True)])
+def test_page_ids_are_backed_and_given_back_as_units(lanes, compat, unified):
+    ops, capi, views = _engine(lanes, layers=8 if unified else 4, ids_per_half=64, compat=compat, unified=unified)
     R = len(views)
     assert R == 8 and capi.get_option(129) == 8          # page ids are backed by lanes, 8 to a buffer at most
     capi.reset_stats()                                   # once: the ledger at the end counts from here
