@@ -62,14 +62,14 @@ if ckt:
                 dst[r["Grid_Size"]].append(float(r["Counter_Value"]))
     shapes = []
     for grid, d in dur.items():
-        moves = int(grid) // 256 // 2 // 64          # grid = moves x 64 regions x 2 tiles (32 KiB block / 16 KiB tile) x 256 threads
+        moves = int(grid) // 256 // 64               # grid = moves x 64 regions x 1 tile (32 KiB block = one 32 KiB tile since round 3) x 256 threads
         algo = 32768 * 64 * moves
         w, f = int(statistics.mean(wr[grid]) * 1024), int(2 * statistics.mean(rd_[grid]) * 1024)
         shapes.append({"moves": moves, "launches": len(d), "avg_us": round(sum(d) / len(d), 1),
                        "algorithmic_read_bytes": algo, "algorithmic_write_bytes": algo, "pmc_write_bytes": w, "pmc_read_bytes": f,
                        "traffic_over_algorithmic": round((w + f) / (2 * algo), 4),
                        "GBps_read_plus_write": round(2 * algo / (sum(d) / len(d)) / 1e3, 1)})
-    json.dump({"kernel": "kvc::compact_blocks_lds_kernel<true>", "geometry": "Llama-3-8B: 64 regions x 32 KiB blocks",
+    json.dump({"kernel": "kvc::compact_blocks_big_kernel<true> (LDS-staged, XCD-aware, non-temporal, 32 KiB tiles)", "geometry": "Llama-3-8B: 64 regions x 32 KiB blocks",
                "note": "rocprofv3 --kernel-trace for durations; WRITE_SIZE and FETCH_SIZE in separate --pmc passes; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B)",
                "per_launch": shapes}, open(f"profiles/{R}_compact_traffic.json", "w"), indent=1)
     shutil.copy(newest("gpurun_out/prof_compact_kt/runc/*_kernel_stats.csv"), f"profiles/{R}_rocprofv3_compact_kernel_stats.csv")
