@@ -192,6 +192,8 @@ def measure(capi, device, steps, warmup, mode, pool_mb, fanout=None, barrier=Non
                 unmapper(offs)
                 per_unmap.append(time.perf_counter() - tb)
         capi.flush_unmaps()   # nothing of the timed work is left owed or in flight on the library's own thread
+        if fanout is not None:
+            fanout.finish()   # ... nor unagreed between the ranks
         if sync:
             sync()
         if barrier:
@@ -747,7 +749,9 @@ def main():
         else:
             dist.init_process_group(backend)
         from kvcached_amd.tp_ipc_util import CollectiveFanout
-        fanout = CollectiveFanout(device=device if backend == "nccl" else "cpu")
+        # the ranks' agreement on call i travels while call i+1 is being broadcast (deferred_status); measure() ends the timed
+        # region with fanout.finish(): nothing is left unchecked inside the bracket
+        fanout = CollectiveFanout(device=device if backend == "nccl" else "cpu", deferred_status=True)
         barrier = dist.barrier
 
     res = measure(capi, device, args.steps, args.warmup, args.mode, args.pool_mb, fanout, barrier, sync, backend=args.backend)

@@ -410,8 +410,14 @@ class CollectiveFanout:
 
     MAX_OFFSETS = 4093  # header + payload = 4096 int64 = 32 KiB, one fixed-size broadcast
 
-    def __init__(self, group=None, src: int = 0, device: Optional[str] = None, park_on_host: bool = False):
-        """park_on_host: the non-src ranks wait for the NEXT command in a helper thread (start_collective_worker). A rank
+    def __init__(self, group=None, src: int = 0, device: Optional[str] = None, park_on_host: bool = False,
+                 deferred_status: bool = False):
+        """deferred_status (SPMD callers that issue commands back to back: bench.py): the status all-reduce of call i is started
+        behind its local (un)map and only WAITED for at the start of call i+1 (or in finish()): the agreement of the ranks
+        overlaps the next call's broadcast instead of standing between two calls. A rank's failure then surfaces one call later -
+        on every rank, as before - and nothing is left unchecked once finish() has returned. The engine relay
+        (start_collective_worker) keeps the synchronous form: the scheduler must know before it hands the pages out.
+        park_on_host: the non-src ranks wait for the NEXT command in a helper thread (start_collective_worker). A rank
         parked inside an RCCL broadcast has that collective sitting enqueued on its GPU, where any device-wide
         synchronisation (torch.cuda.synchronize, the library's own hipDeviceSynchronize) would wait for the scheduler's next
         KV command; so a one-word gloo broadcast wakes the followers first and the RCCL broadcast is only entered when src
@@ -435,6 +441,9 @@ class CollectiveFanout:
         self._stage_np = self._stage.numpy()
         self._status_host = torch.zeros(1, dtype=torch.int64, pin_memory=on_gpu) if on_gpu else self._status
         self._on_gpu = on_gpu
+        self._deferred = bool(deferred_status)
+        self._pending = None          # (work, status tensor) of the previous call's all-reduce, deferred mode
+        self._stage_free = None       # event behind the last H2D copy out of the pinned staging buffer (src rank, GPU)
         self._wake_group = None
         if park_on_host and on_gpu and self.world_size > 1:
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
@@ -448,11 +457,17 @@ class CollectiveFanout:
             n = len(offsets)
             if n > self.MAX_OFFSETS:
                 raise ValueError(f"at most {self.MAX_OFFSETS} offsets per collective call")
+            if self._stage_free is not None:   # the previous message has left the staging buffer (it has, as a rule, long ago)
+                self._stage_free.synchronize()
             st = self._stage_np
             st[0], st[1], st[2] = cmd, group_id, n
             st[3:3 + n] = offsets
             if self._on_gpu:
                 self._buf[:3 + n].copy_(self._stage[:3 + n], non_blocking=True)
+                if self._deferred:             # (synchronous mode: the status read-back of every call is that synchronisation)
+                    if self._stage_free is None:
+                        self._stage_free = torch.cuda.Event()
+                    self._stage_free.record(torch.cuda.current_stream(self._buf.device))
         if self._wake_group is not None:   # host-side wake-up: nobody waits inside a GPU collective for a command that is not there yet
             dist.broadcast(self._wake, src=dist.get_global_rank(self.group, self.src) if self.group else self.src, group=self._wake_group)
         dist.broadcast(self._buf, src=dist.get_global_rank(self.group, self.src) if self.group else self.src,
@@ -465,7 +480,29 @@ class CollectiveFanout:
         n = int(st[2])
         return int(st[0]), int(st[1]), st[3:3 + n].tolist()
 
+    def _check_pending(self) -> None:
+        """Deferred mode: the verdict of the previous call (raises on every rank if any rank had failed)."""
+        pending, self._pending = self._pending, None
+        if pending is None:
+            return
+        work, status = pending
+        work.wait()
+        if int(status.item()) != 1:
+            raise RuntimeError("a tensor-parallel rank failed to (un)map KV pages (reported by the call that followed)")
+
+    def finish(self) -> None:
+        """Deferred mode: wait for the agreement on the LAST call. A no-op otherwise."""
+        self._check_pending()
+
     def _finish(self, ok: bool) -> None:
+        if self._deferred:
+            # a status tensor of its own per call: the previous one may still be travelling
+            status = self._torch.ones(1, dtype=self._torch.int64, device=self.device)
+            if not ok:
+                status.zero_()
+            work = self._dist.all_reduce(status, op=self._dist.ReduceOp.MIN, group=self.group, async_op=True)
+            self._pending = (work, status)
+            return
         if self._on_gpu:
             self._status_host[0] = 1 if ok else 0
             self._status.copy_(self._status_host, non_blocking=True)
@@ -491,6 +528,7 @@ class CollectiveFanout:
     def run(self, cmd: int, offsets: Sequence[int] = (), group_id: int = 0, raise_on_failure: bool = True):
         """Broadcast (cmd, group_id, offsets) from `src`, apply locally, agree on success. Returns the offsets (or, with
         raise_on_failure=False, whether every rank succeeded)."""
+        self._check_pending()
         cmd, group_id, offs = self._exchange(cmd, offsets, group_id)
         ok = self._apply(cmd, offs, group_id)
         if raise_on_failure:

@@ -34,7 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_channel():
     from kvcached_amd import capi
-    assert capi.lib.kvc_abi_version() == 4
+    want = int(re.search(r"#define\s+KVC_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert capi.lib.kvc_abi_version() == want == 5          # (5: kvc_quiesce_*, KVC_OPT_UNMAP_INVALIDATION_US)
     assert capi.lib.kvc_set_option(999, 1) == capi.KVC_E_INVALID
     assert capi.last_error() == "unknown option"
     assert capi.lib.kvc_get_device(None, None) == capi.KVC_E_INVALID  # not initialised

@@ -129,6 +129,9 @@ _CONFIGS += [("drm", "lazy", 0, 64, "KVCACHED_DEFER_UNMAP_SHOOTDOWN=true"), ("dr
              ("drm", "compat", 0, 1, "KVCACHED_PRT=false")]
 # compat, relaxed: the invalidation an unmap owes trails the call by at most 300 us; the pages wait for it un-scrubbed, un-offered
 _CONFIGS += [(b, "compat", 0, ck, "KVCACHED_UNMAP_INVALIDATION_US=300") for b, ck in (("drm", 64), ("drm", 1), ("hybrid", 1), ("hip", 1))]
+# the two layers of this geometry make every page id a lane of two pages in the drm rows above with 64-page extents;
+# here: lanes switched off (slot-by-slot backing with run-sized extents), and two lanes to a buffer (partly used buffers all the time)
+_CONFIGS += [("drm", mode, 0, 64, sw) for mode in ("lazy", "compat") for sw in ("KVCACHED_LANE_EXTENTS=false", "KVCACHED_LANES_PER_BUFFER=2")]
 
 
 @pytest.mark.parametrize("backend,mode,async_unmap,extent_pages,switch", _CONFIGS)
@@ -146,6 +149,8 @@ def test_pages_are_private_and_zeroed_in_every_shipped_configuration(vmm, monkey
     if switch:
         monkeypatch.setenv(*switch.split("="))
     ops, capi, ts = _setup(vmm, layers=2, per_layer=64 * PAGE, backfill=(mode == "compat"), kv=1, unified=False)
+    lanes_expected = backend == "drm" and extent_pages > 1 and not async_unmap and switch != "KVCACHED_LANE_EXTENTS=false"
+    assert (capi.get_option(129) > 0) == lanes_expected, capi.get_option(129)
     # PRT behind unbacked VA: the compat default on the drm backend; lazy mode leaves unbacked VA unmapped unless asked
     assert capi.get_option(capi.OPT_PRT) == int(backend == "drm" and (switch == "KVCACHED_PRT=true" or (mode == "compat" and switch != "KVCACHED_PRT=false")))
     want_backend = {"drm": 3, "hybrid": 2, "hip": 0}[backend]

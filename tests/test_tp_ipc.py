@@ -154,6 +154,65 @@ def _collective_worker(rank, world, port, q):
         q.put((rank, "ERR", repr(e), 0, False))
 
 
+def _deferred_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KVCACHED_LOG_LEVEL="ERROR",
+                          KVCACHED_IPC_NAME=f"kvc_test_defer_{port}_{rank}")
+        sys.path.insert(0, T.REPO)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from kvcached_amd import capi, vmm_ops
+        from kvcached_amd.tp_ipc_util import CollectiveFanout
+        vmm_ops.init_kvcached("cpu", PAGE, False)
+        vmm_ops.create_kv_tensors(32 * MiB, 1, "cpu", 2, 2, 0, False)
+        capi.reset_stats()
+        fan = CollectiveFanout(deferred_status=True)
+        seen = []
+        for i in range(5):                                      # back to back: the agreement on call i is waited for by call i + 1
+            seen.append(fan.map_to_kv_tensors([i * PAGE, 7 * PAGE] if rank == 0 else []))
+            fan.unmap_from_kv_tensors([7 * PAGE, i * PAGE] if rank == 0 else [])
+        fan.finish()
+        st = capi.get_stats()
+        events = []
+        if rank == 1:
+            vmm_ops.shutdown_kvcached()                         # rank 1 loses its allocator: its next local map fails
+        try:
+            fan.map_to_kv_tensors([6 * PAGE] if rank == 0 else [])        # returns on rank 0: nobody has been asked yet
+            events.append("call returned")
+            fan.finish()                                                   # ... and here every rank learns of it
+            events.append("finish returned")
+        except RuntimeError:
+            events.append("raised")
+        q.put((rank, seen, st["pages_mapped"], st["pages_unmapped"], events))
+        if rank == 0:
+            vmm_ops.shutdown_kvcached()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, "ERR", repr(e), 0, []))
+
+
+def test_collective_fanout_with_the_agreement_deferred_by_one_call():
+    """deferred_status (bench.py at N > 1): the status all-reduce of call i is started behind its local (un)map and waited for at the
+    start of call i + 1 or in finish(); every rank still maps exactly rank 0's offsets, and a rank's failure is an exception on
+    EVERY rank - one call later, at the latest in finish()."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_deferred_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, seen, mapped, unmapped, events in results:
+        assert seen == [[i * PAGE, 7 * PAGE] for i in range(5)], results
+        assert mapped == 10 * 2 * 2 and unmapped == 10 * 2 * 2
+        assert events == ["call returned", "raised"], (rank, events)
+
+
 def test_collective_fanout_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
