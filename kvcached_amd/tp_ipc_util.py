@@ -411,12 +411,15 @@ class CollectiveFanout:
     MAX_OFFSETS = 4093  # header + payload = 4096 int64 = 32 KiB, one fixed-size broadcast
 
     def __init__(self, group=None, src: int = 0, device: Optional[str] = None, park_on_host: bool = False,
-                 deferred_status: bool = False):
-        """deferred_status (SPMD callers that issue commands back to back: bench.py): the status all-reduce of call i is started
-        behind its local (un)map and only WAITED for at the start of call i+1 (or in finish()): the agreement of the ranks
-        overlaps the next call's broadcast instead of standing between two calls. A rank's failure then surfaces one call later -
-        on every rank, as before - and nothing is left unchecked once finish() has returned. The engine relay
-        (start_collective_worker) keeps the synchronous form: the scheduler must know before it hands the pages out.
+                 deferred_status: bool = False, status_every: int = 8):
+        """deferred_status (SPMD callers that issue commands back to back: bench.py): the ranks' agreement is pipelined instead of
+        standing between two calls. Every rank folds the outcome of its local (un)maps into one flag; every `status_every` calls
+        that flag goes into an asynchronous all-reduce(min), whose verdict is read when the NEXT window closes (or in finish()).
+        A rank's failure raises on that rank at once (its own exception is not swallowed in this mode) and on every other rank
+        within two windows, at the latest in finish(); nothing is left unchecked once finish() has returned. Measured at world
+        size 1 over RCCL (benchmarks/probe_fanout_cost.py): a synchronous status costs 57 us per call, a per-call deferred one 70
+        (its read-back waits for a kernel that has to get onto a GPU busy zeroing pages), the window 3. The engine relay
+        (start_collective_worker) keeps the synchronous form: a scheduler must know before it hands the pages out.
         park_on_host: the non-src ranks wait for the NEXT command in a helper thread (start_collective_worker). A rank
         parked inside an RCCL broadcast has that collective sitting enqueued on its GPU, where any device-wide
         synchronisation (torch.cuda.synchronize, the library's own hipDeviceSynchronize) would wait for the scheduler's next
@@ -443,6 +446,12 @@ class CollectiveFanout:
         self._on_gpu = on_gpu
         self._deferred = bool(deferred_status)
         self._pending = None          # (work, status tensor) of the previous call's all-reduce, deferred mode
+        # deferred mode: two status words taken in turn (the previous one may still be travelling), refreshed from constants
+        self._status2 = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
+        self._const = {True: torch.ones(1, dtype=torch.int64, device=device), False: torch.zeros(1, dtype=torch.int64, device=device)}
+        self._turn = 0
+        self._every = max(1, int(status_every))
+        self._calls_in_window, self._ok_in_window = 0, True
         self._stage_free = None       # event behind the last H2D copy out of the pinned staging buffer (src rank, GPU)
         self._wake_group = None
         if park_on_host and on_gpu and self.world_size > 1:
@@ -478,6 +487,8 @@ class CollectiveFanout:
             torch.cuda.current_stream(self._buf.device).synchronize()   # the stream of the buffer's GPU, whatever this thread's current device is
         st = self._stage_np
         n = int(st[2])
+        if self._deferred and int(st[0]) in (CMD_MAP, CMD_UNMAP):
+            return int(st[0]), int(st[1]), st[3:3 + n]       # (a view of the staging buffer: valid until the next call)
         return int(st[0]), int(st[1]), st[3:3 + n].tolist()
 
     def _check_pending(self) -> None:
@@ -490,18 +501,28 @@ class CollectiveFanout:
         if int(status.item()) != 1:
             raise RuntimeError("a tensor-parallel rank failed to (un)map KV pages (reported by the call that followed)")
 
+    def _close_window(self) -> None:
+        self._check_pending()          # the verdict of the window before this one (its all-reduce has had a whole window to finish)
+        self._turn ^= 1
+        status = self._status2[self._turn]
+        status.copy_(self._const[self._ok_in_window], non_blocking=True)
+        work = self._dist.all_reduce(status, op=self._dist.ReduceOp.MIN, group=self.group, async_op=True)
+        self._pending = (work, status)
+        self._calls_in_window, self._ok_in_window = 0, True
+
     def finish(self) -> None:
-        """Deferred mode: wait for the agreement on the LAST call. A no-op otherwise."""
+        """Deferred mode: agree on everything up to now (every rank calls it). A no-op otherwise."""
+        if not self._deferred:
+            return
+        self._close_window()
         self._check_pending()
 
     def _finish(self, ok: bool) -> None:
         if self._deferred:
-            # a status tensor of its own per call: the previous one may still be travelling
-            status = self._torch.ones(1, dtype=self._torch.int64, device=self.device)
-            if not ok:
-                status.zero_()
-            work = self._dist.all_reduce(status, op=self._dist.ReduceOp.MIN, group=self.group, async_op=True)
-            self._pending = (work, status)
+            self._ok_in_window = self._ok_in_window and bool(ok)
+            self._calls_in_window += 1
+            if self._calls_in_window >= self._every:
+                self._close_window()
             return
         if self._on_gpu:
             self._status_host[0] = 1 if ok else 0
@@ -511,6 +532,26 @@ class CollectiveFanout:
         self._dist.all_reduce(self._status, op=self._dist.ReduceOp.MIN, group=self.group)
         if int(self._status.item()) != 1:
             raise RuntimeError("a tensor-parallel rank failed to (un)map KV pages")
+
+    def _apply_staged(self, cmd: int, n: int, group_id: int) -> bool:
+        """deferred mode: the offsets go to the C ABI as they lie in the staging buffer (no list, no pybind conversion: 40 us of a
+        1024-offset call)."""
+        try:
+            from kvcached_amd import capi
+            import ctypes
+            ptr = ctypes.cast(self._stage_np[3:].ctypes.data, ctypes.POINTER(ctypes.c_int64))
+            if cmd == CMD_MAP:
+                capi.check(capi.lib.kvc_map_to_kv_tensors(ptr, n, group_id))
+                return True
+            if cmd == CMD_UNMAP:
+                capi.check(capi.lib.kvc_unmap_from_kv_tensors(ptr, n, group_id))
+                return True
+            return self._apply(cmd, [], group_id)
+        except Exception as e:
+            print(f"rank {self.rank}: collective (un)map failed: {e}")
+            self._ok_in_window = False   # the others learn of it when the window closes ...
+            self._local_failure = e      # ... this rank, from run(), now
+            return False
 
     def _apply(self, cmd: int, offs: List[int], group_id: int) -> bool:
         try:
@@ -526,10 +567,17 @@ class CollectiveFanout:
             return False
 
     def run(self, cmd: int, offsets: Sequence[int] = (), group_id: int = 0, raise_on_failure: bool = True):
-        """Broadcast (cmd, group_id, offsets) from `src`, apply locally, agree on success. Returns the offsets (or, with
-        raise_on_failure=False, whether every rank succeeded)."""
-        self._check_pending()
+        """Broadcast (cmd, group_id, offsets) from `src`, apply locally, agree on success. Returns the offsets - a list, or in
+        deferred mode a numpy view of the message that is valid until the next call - (or, with raise_on_failure=False, whether
+        every rank succeeded)."""
         cmd, group_id, offs = self._exchange(cmd, offsets, group_id)
+        if self._deferred and cmd in (CMD_MAP, CMD_UNMAP):
+            self._local_failure = None
+            ok = self._apply_staged(cmd, len(offs), group_id)
+            self._finish(ok)
+            if self._local_failure is not None:
+                raise RuntimeError(f"rank {self.rank} failed to (un)map KV pages: {self._local_failure}")
+            return offs
         ok = self._apply(cmd, offs, group_id)
         if raise_on_failure:
             self._finish(ok)

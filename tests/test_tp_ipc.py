@@ -166,10 +166,10 @@ def _deferred_worker(rank, world, port, q):
         vmm_ops.init_kvcached("cpu", PAGE, False)
         vmm_ops.create_kv_tensors(32 * MiB, 1, "cpu", 2, 2, 0, False)
         capi.reset_stats()
-        fan = CollectiveFanout(deferred_status=True)
+        fan = CollectiveFanout(deferred_status=True, status_every=4)
         seen = []
-        for i in range(5):                                      # back to back: the agreement on call i is waited for by call i + 1
-            seen.append(fan.map_to_kv_tensors([i * PAGE, 7 * PAGE] if rank == 0 else []))
+        for i in range(5):                                      # 10 calls back to back: two windows close on the way
+            seen.append([int(o) for o in fan.map_to_kv_tensors([i * PAGE, 7 * PAGE] if rank == 0 else [])])
             fan.unmap_from_kv_tensors([7 * PAGE, i * PAGE] if rank == 0 else [])
         fan.finish()
         st = capi.get_stats()
@@ -177,12 +177,15 @@ def _deferred_worker(rank, world, port, q):
         if rank == 1:
             vmm_ops.shutdown_kvcached()                         # rank 1 loses its allocator: its next local map fails
         try:
-            fan.map_to_kv_tensors([6 * PAGE] if rank == 0 else [])        # returns on rank 0: nobody has been asked yet
+            fan.map_to_kv_tensors([6 * PAGE] if rank == 0 else [])        # raises on rank 1 at once; returns on rank 0
             events.append("call returned")
+        except RuntimeError:
+            events.append("call raised")
+        try:
             fan.finish()                                                   # ... and here every rank learns of it
             events.append("finish returned")
         except RuntimeError:
-            events.append("raised")
+            events.append("finish raised")
         q.put((rank, seen, st["pages_mapped"], st["pages_unmapped"], events))
         if rank == 0:
             vmm_ops.shutdown_kvcached()
@@ -191,10 +194,10 @@ def _deferred_worker(rank, world, port, q):
         q.put((rank, "ERR", repr(e), 0, []))
 
 
-def test_collective_fanout_with_the_agreement_deferred_by_one_call():
-    """deferred_status (bench.py at N > 1): the status all-reduce of call i is started behind its local (un)map and waited for at the
-    start of call i + 1 or in finish(); every rank still maps exactly rank 0's offsets, and a rank's failure is an exception on
-    EVERY rank - one call later, at the latest in finish()."""
+def test_collective_fanout_with_the_agreement_pipelined():
+    """deferred_status (bench.py at N > 1): the outcome of the local (un)maps goes into one all-reduce per window of calls, read
+    when the next window closes or in finish(). Every rank still maps exactly rank 0's offsets; a rank's failure raises on that
+    rank at once and on EVERY rank in finish() at the latest."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     import socket
@@ -210,7 +213,7 @@ def test_collective_fanout_with_the_agreement_deferred_by_one_call():
     for rank, seen, mapped, unmapped, events in results:
         assert seen == [[i * PAGE, 7 * PAGE] for i in range(5)], results
         assert mapped == 10 * 2 * 2 and unmapped == 10 * 2 * 2
-        assert events == ["call returned", "raised"], (rank, events)
+        assert events == (["call returned", "finish raised"] if rank == 0 else ["call raised", "finish raised"]), (rank, events)
 
 
 def test_collective_fanout_two_ranks_gloo():
