@@ -311,18 +311,13 @@ void GpuContext::housekeeping() {
   // created here would be trimmed at the next tick, for ever)
   size_t reserve_b = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load()));
   ExtentPool *primary = primary_pool_.load();
-  // An engine that has had NOTHING mapped for KVCACHED_RESERVE_IDLE_S (default 10 s) gives its reserve back as well: idle
-  // memory is what a co-located engine could use (the reference releases every page on unmap, csrc/page.cpp:17). The reserve
-  // comes back with the first tick after something is mapped again.
+  // An engine that has not mapped or unmapped anything for KVCACHED_RESERVE_IDLE_S (default 10 s) gives its reserve back as well:
+  // idle memory is what a co-located engine could use (the reference releases every page on unmap, csrc/page.cpp:17). The
+  // reserve comes back with the first ticks after the next call. (Not "nothing mapped": an engine's prealloc thread keeps a few
+  // page ids mapped at all times.)
   if (primary) {
-    const auto fp = primary->footprint();
-    if (fp.out_pages != 0 || limbo_bytes_.load() != 0) {
-      nothing_mapped_since_ns_ = 0;
-    } else if (nothing_mapped_since_ns_ == 0) {
-      nothing_mapped_since_ns_ = now_ns();
-    } else if (now_ns() - nothing_mapped_since_ns_ >= std::max<int64_t>(1, env_i64("KVCACHED_RESERVE_IDLE_S", 10)) * 1000000000ll) {
-      reserve_b = 0;
-    }
+    const int64_t last = fg_last_ns_.load();
+    if (fg_active_.load() == 0 && last != 0 && now_ns() - last >= std::max<int64_t>(1, env_i64("KVCACHED_RESERVE_IDLE_S", 10)) * 1000000000ll) reserve_b = 0;
   }
   // The reserve follows demand. What a map call has to CREATE it pays for on its caller's thread - 2 us per
   // buffer on VRAM the kernel has wiped, but ~50-80 us per 2 MiB on VRAM it has not handed out yet (cleared inside the

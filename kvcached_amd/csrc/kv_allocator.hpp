@@ -228,7 +228,6 @@ private:
   std::atomic<ExtentPool *> primary_pool_{nullptr};
   // the reserve follows demand (housekeeping(), one thread): units created on callers' paths per tick over the last second
   std::mutex hk_mu_;
-  int64_t nothing_mapped_since_ns_ = 0;
   static constexpr size_t kDemandTicks = 10;
   ExtentPool *demand_pool_ = nullptr;
   size_t demand_seen_ = 0, demand_window_[kDemandTicks] = {}, demand_tick_ = 0, demand_quiet_ticks_ = 0, reserve_boost_units_ = 0;

@@ -476,6 +476,51 @@ def test_the_reserve_follows_demand(monkeypatch):
     assert st["handles_created"] == st["handles_released"]
 
 
+def test_an_idle_engine_gives_its_reserve_back(monkeypatch):
+    """the pre-created reserve is idle memory a co-located engine cannot see. An engine that has not mapped or unmapped
+    anything for KVCACHED_RESERVE_IDLE_S gives it back (the reference releases every page on unmap: csrc/page.cpp:17) and gets it again with the
+    first ticks after the next call."""
+    import kvcached_amd.kv_cache_manager as kcm
+    from kvcached_amd import capi, vmm_ops
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "256")
+    monkeypatch.setenv("KVCACHED_POOL_IDLE_MS", "100")
+    monkeypatch.setenv("KVCACHED_RESERVE_IDLE_S", "1")
+    monkeypatch.setattr(kcm, "CONTIGUOUS_LAYOUT", False)
+    monkeypatch.setattr(kcm, "PAGE_PREALLOC_ENABLED", True)
+    vmm_ops.init_kvcached(DEV, T.PAGE, False)
+    capi.reset_stats()
+    try:
+        vmm_ops.create_kv_tensors(128 * T.PAGE * 2, 1, DEV, 4, 2, 0, False)
+        m = kcm.KVCacheManager(num_blocks=128 * 64, block_size=16, cell_size=2048, num_layers=4)
+        assert m._post_init_done.wait(10)
+        if capi.get_option(108) != 3 or capi.get_option(110) != 1:
+            pytest.skip("the reserve is pre-created with the drm backend and pages straight from KFD")
+        # whole idle buffers (free lanes of a buffer that a still-mapped page id pins cannot go back: they are handed out first instead)
+        idle = lambda: capi.get_option(capi.OPT_POOL_HELD_PAGES) - capi.get_option(capi.OPT_POOL_OUT_PAGES) - capi.get_option(capi.OPT_POOL_FREE_PIECES)   # noqa: E731
+        ids = m.alloc(24 * 64)                                        # more than the prealloc thread keeps ready: map calls happen
+        time.sleep(0.4)
+        assert idle() >= 64                                           # in use: the reserve stands (128 pages, some of them free lanes of partly used buffers)
+        m.free(ids)                                                   # more than stay mapped for reuse: unmap calls happen (no trim(): that empties the pool by itself)
+        t0 = time.time()
+        time.sleep(0.4)
+        assert idle() >= 64                                           # a moment after the last call: still there
+        while idle() > 0 and time.time() - t0 < 8:
+            time.sleep(0.1)
+        assert idle() == 0, (idle(), time.time() - t0)                # the idle second is over: gone
+        ids = m.alloc(24 * 64)                                        # in use again: it comes back
+        t0 = time.time()
+        while idle() < 64 and time.time() - t0 < 5:
+            time.sleep(0.1)
+        assert idle() >= 64, idle()
+        m.free(ids)
+        m.trim()
+    finally:
+        m = None
+        vmm_ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_golden_trace_with_async_unmap(monkeypatch):
     """Bookkeeping is synchronous, so the reference's golden trace (block ids, page offsets, counters) is still
     bit-exact with KVC_OPT_ASYNC_UNMAP on; after a flush the physical ledger matches the synchronous run."""
