@@ -1510,22 +1510,26 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
     throw;
   }
   stats().pages_mapped += (int64_t)(done.size() + kept.size());
-  if (cold && pool->creations() > 0 && !imported && !exportable_) cold_start_reserve(pool); // (the reserve belongs to the engine's own pool, not to the exportable twin)
+  (void)cold;
+  if (pool->creations() > 0 && !imported && !exportable_) cold_start_reserve(pool); // (the reserve belongs to the engine's own pool, not to the exportable twin)
 }
 
-// Cold start: the first extents a pool ever had to create bring the reserve along, sized like themselves
-// (KVCACHED_PHYS_RESERVE_MB): pages that come back are zeroed behind the unmap, and a free()+alloc() cycle
-// that can draw on an idle batch never waits for that fill. Where a housekeeping thread exists (an engine: PageAllocator's
-// watcher tops the reserve up, 256 pages per 100 ms tick) the caller only pays for as much as one tick would have made -
-// the whole reserve on the first map call was 7.6 ms in the smoke run and ~80 ms on VRAM the kernel has not wiped; a bare
-// C-ABI caller has no such thread and gets it all at once.
+// Cold start: the first map calls of an allocator bring the reserve along (KVCACHED_PHYS_RESERVE_MB): pages
+// that come back are zeroed behind the unmap, and a free()+alloc() cycle that can draw on an idle batch never waits for that
+// fill. In instalments of 512 MiB per map call until it has stood once (the whole 2 GiB inside the first call was
+// 7.6 ms in the smoke run and ~80 ms on VRAM the kernel has not wiped) - a bare C-ABI caller has no housekeeping thread to make
+// it; where one exists (an engine: PageAllocator's watcher, 512 MiB per 100 ms tick) it takes over after the first instalment
+// and keeps it up from then on.
 void KvAllocator::cold_start_reserve(ExtentPool *pool) {
+  if (reserve_built_) return;
   const size_t unit = pool->page_bytes();
-  size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / unit;
-  if (!want) return;
-  size_t now = want;
-  if (ctx_->has_housekeeper()) now = std::min(want, std::max<size_t>(1, (512u << 20) / unit));
-  (void)pool->refill_reserve(want, now);
+  const size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / unit;
+  if (!want || pool->idle_bytes() / unit >= want) {
+    reserve_built_ = true;
+    return;
+  }
+  (void)pool->refill_reserve(want, std::max<size_t>(1, (512u << 20) / unit));
+  if (ctx_->has_housekeeper()) reserve_built_ = true; // (the thread makes the rest)
 }
 
 void KvAllocator::unmap_slots(const std::vector<Slot> &slots) {
@@ -1963,7 +1967,8 @@ bool KvAllocator::try_map_lanes(const offset_t *offsets, size_t n) {
   }
   stats().pages_mapped += (int64_t)(ids * R);
   if (prescrubbed) stats().pages_prescrubbed += (int64_t)prescrubbed;
-  if (cold && pool->creations() > 0) cold_start_reserve(pool);
+  (void)cold;
+  if (pool->creations() > 0) cold_start_reserve(pool);
   return true;
 }
 

@@ -409,6 +409,7 @@ private:
   std::vector<Row> rows_;        // layer-major, K then V: the order slots_for() lists the slots of one offset in
   size_t ids_per_row_ = 0;       // page ids a row has room for
   ExtentPool *lane_pool_ = nullptr;
+  bool reserve_built_ = false;   // the cold-start instalments of the reserve are over (cold_start_reserve)
   // async unmap state (guarded by mu_)
   std::deque<Slot> pending_;
   std::condition_variable pending_cv_, drained_cv_;
