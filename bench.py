@@ -460,13 +460,14 @@ def reference_on_box(steps, warmup, burst=False):
 def shared_pool_leg(rank, world, device, backend, rehearsal):
     """BASELINE.json configs[3]: "TP=8 shared KV pool: rank-0 create + IPC export, ranks 1-7 map over xGMI" (the reference's own
     harness only fans offsets out: benchmarks/bench_tp_ipc/kvcached_tp_ipc_benchmark.py:117-212, kvcached/tp_ipc_util.py:173-192).
-    Llama-3-8B geometry on every rank (32 layers x K/V, same VA layout). Per round: rank 0 backs k page ids with exportable
-    pages and writes a signature into each of them; SharedPoolChannel.share(): offsets over the group's collective (RCCL
-    broadcast), one dmabuf fd per 2 MiB slot over SCM_RIGHTS, every other rank imports and maps the SAME physical pages at the same
-    offsets; each of them reads the signature through its own mapping with a kernel on ITS GPU (rank 0's memory: the read
-    crosses xGMI) and the ranks agree on the result; everything is unmapped again. Reports ms per page id and which import path
-    the peers took (straight into KFD + DRM, or the runtime's import - the fallback for a buffer the direct path refuses)."""
-    import numpy as np
+    Llama-3-8B geometry on every rank (32 layers x K/V, same VA layout). Per round: rank 0 backs k page ids and writes a
+    signature into each of them; SharedPoolChannel.share(): offsets over the group's collective (RCCL broadcast), descriptors over
+    SCM_RIGHTS, every other rank imports and maps the SAME physical pages at the same offsets; each of them reads the signature
+    through its own mapping with a kernel on ITS GPU (rank 0's memory: the read crosses xGMI) and the ranks agree on the result;
+    everything is unmapped again. Twice: with page ids as units (ONE dmabuf per page id: the buffer its lane lives in, DESIGN.md
+    §4.11) and slot by slot (one per 2 MiB slot, exportable single pages: round 2's form). Reports ms per page id and which
+    import path the peers took (straight into KFD + DRM, or the runtime's import - the fallback for a buffer the direct path
+    refuses)."""
     import torch
     import torch.distributed as dist
     from kvcached_amd import capi, vmm_ops
@@ -474,79 +475,90 @@ def shared_pool_leg(rank, world, device, backend, rehearsal):
     L, half = 32, 64
     cdev = device if backend == "nccl" else "cpu"
     fan = CollectiveFanout(device=cdev)
-    exporter = importer = None
-    if rehearsal:   # the library's cpu device maps nothing and exports nothing: stand-ins that prove the control flow and that fds travel
-        exporter = lambda offs, gid: [os.memfd_create(f"kvc_rehearsal_{o}") for o in offs for _ in range(2 * L)]   # noqa: E731
+    red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], dtype=torch.float64, device=cdev))   # noqa: E731
+    med = lambda v: round(statistics.median(v) * 1e3, 3)   # noqa: E731
+    out = {"ranks": world, "layers": L, "transport": f"{backend} broadcast of the offsets + all-reduce(min) of the status; dmabuf fds over SCM_RIGHTS"}
+    for units in ("page_ids", "slots"):
+        exporter = importer = None
         seen = []
-        importer = lambda offs, fds, gid: seen.append((len(offs), sum(1 for fd in fds if os.fstat(fd).st_size == 0)))   # noqa: E731
-    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
-    vmm_ops.init_kvcached(device, PAGE, False)
-    out = {"ranks": world, "layers": L, "transport": f"{backend} broadcast of the offsets + all-reduce(min) of the status; one dmabuf fd per 2 MiB slot over SCM_RIGHTS"}
-    try:
-        ts = vmm_ops.create_kv_tensors(2 * half * PAGE, 8, device, L, 2, 0, False)     # int64 elements
-        chan = SharedPoolChannel(fan, exporter=exporter, importer=importer)
-        epp = PAGE // 8
-        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], dtype=torch.float64, device=cdev))   # noqa: E731
-        for k in (1, 8):
-            back, share, verify, ok_all = [], [], [], True
-            for it in range(6):
-                ids = [(it * k + j) % half for j in range(k)]
-                offs = [p * PAGE for p in ids]
-                sig = 0x5EED0000 + 977 * it + k
-                dist.barrier()
-                t0 = time.perf_counter()
-                if rank == 0:
-                    capi.map_to_kv_tensors(offs)
-                    if not rehearsal:
-                        for t in (ts[0], ts[L - 1]):                      # first K row and last V row of every page id
-                            for p in ids:
-                                t[p * epp] = sig + p
-                                t[(half + p) * epp + 5] = sig - p
-                        torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                tm = chan.share(offs)
-                t2 = time.perf_counter()
-                good = 1.0
-                if rank != 0 and not rehearsal:
-                    for t in (ts[0], ts[L - 1]):
-                        idx = torch.tensor([p * epp for p in ids] + [(half + p) * epp + 5 for p in ids], device=device)
-                        got = (t[idx] + 0).cpu().tolist()              # a gather kernel on THIS rank's GPU reads rank 0's pages
-                        good = good if got == [sig + p for p in ids] + [sig - p for p in ids] else 0.0
-                elif rank != 0:
-                    good = 1.0 if seen and seen[-1] == (k, k * 2 * L) else 0.0
-                t3 = time.perf_counter()
-                ok_all = ok_all and red(good, dist.ReduceOp.MIN) == 1.0
-                if rank != 0:
-                    capi.unmap_from_kv_tensors(offs)                      # the imports are dropped first ...
-                dist.barrier()
-                if rank == 0:
-                    capi.unmap_from_kv_tensors(offs)                      # ... then the owner gives the pages back
-                if it:                                                    # (the first round warms sockets and pools)
-                    back.append(t1 - t0)
-                    share.append(red(t2 - t1, dist.ReduceOp.MAX))
-                    verify.append(red(t3 - t2, dist.ReduceOp.MAX))
-            med = lambda v: round(statistics.median(v) * 1e3, 3)   # noqa: E731
-            out[f"{k}_page_ids"] = {"slots_2MiB": k * 2 * L, "rank0_back_ms_p50": med(back),
-                                    "export_ship_import_map_ms_p50_slowest_rank": med(share),
-                                    "ms_per_page_id": round(statistics.median(share) * 1e3 / k, 3),
-                                    "us_per_slot_per_peer": round(statistics.median(share) * 1e6 / (k * 2 * L) / max(1, world - 1), 2),
-                                    "peers_read_rank0_signature_ms_p50": med(verify), "signature_seen_by_every_peer": ok_all}
-        # which way the peers' imports went (each rank reports its own counters; rank 0 imports nothing)
-        mine = torch.tensor([float(capi.get_option(163)), float(capi.get_option(164))], dtype=torch.float64, device=cdev)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        out["imports_by_rank"] = [{"rank": r, "straight_into_KFD_and_DRM": int(e[0]), "through_the_runtime_ROCr": int(e[1])} for r, e in enumerate(every)]
-        gpus = torch.tensor([float(torch.cuda.current_device()) if not rehearsal else -1.0], dtype=torch.float64, device=cdev)
-        seen_gpus = [torch.zeros_like(gpus) for _ in range(world)]
-        dist.all_gather(seen_gpus, gpus)
-        distinct = len({int(g.item()) for g in seen_gpus})
-        out["gpus_used"] = distinct if not rehearsal else 0
-        out["what"] = ("cross-GPU: rank 0's pages are read by the peers over xGMI" if distinct == world and not rehearsal else
-                       "REHEARSAL on the library's cpu device: offsets and file descriptors travel, nothing is mapped" if rehearsal else
-                       f"REHEARSAL: {world} ranks share {distinct} GPU(s) - the export/ship/import/map machinery runs end to end, but nothing crosses xGMI")
-        chan.close()
-    finally:
-        vmm_ops.shutdown_kvcached()
+        if rehearsal:   # the library's cpu device maps nothing and exports nothing: stand-ins that prove the control flow and that fds travel
+            per = 1 if units == "page_ids" else 2 * L      # (the stand-in exports one descriptor per page id: nothing here knows about buffers)
+            exporter = lambda offs, gid, per=per: [os.memfd_create(f"kvc_rehearsal_{o}") for o in offs for _ in range(per)]   # noqa: E731
+            importer = lambda offs, fds, gid, meta: seen.append((len(offs), sum(1 for fd in fds if os.fstat(fd).st_size == 0)))   # noqa: E731
+        if units == "slots":
+            os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+        else:
+            os.environ.pop("KVCACHED_EXPORTABLE_HANDLES", None)
+        res = {}
+        try:
+            vmm_ops.init_kvcached(device, PAGE, False)
+            ts = vmm_ops.create_kv_tensors(2 * half * PAGE, 8, device, L, 2, 0, False)     # int64 elements
+            imp0 = (capi.get_option(163), capi.get_option(164))
+            chan = SharedPoolChannel(fan, exporter=exporter, importer=importer, units=units)
+            epp = PAGE // 8
+            for k in (1, 8):
+                back, share, verify, ok_all = [], [], [], True
+                for it in range(6):
+                    ids = [(it * k + j) % half for j in range(k)]
+                    offs = [p * PAGE for p in ids]
+                    sig = 0x5EED0000 + 977 * it + k
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    if rank == 0:
+                        capi.map_to_kv_tensors(offs)
+                        if not rehearsal:
+                            for t in (ts[0], ts[L - 1]):                      # first K row and last V row of every page id
+                                for p in ids:
+                                    t[p * epp] = sig + p
+                                    t[(half + p) * epp + 5] = sig - p
+                            torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    chan.share(offs)
+                    t2 = time.perf_counter()
+                    good = 1.0
+                    if rank != 0 and not rehearsal:
+                        for t in (ts[0], ts[L - 1]):
+                            idx = torch.tensor([p * epp for p in ids] + [(half + p) * epp + 5 for p in ids], device=device)
+                            got = (t[idx] + 0).cpu().tolist()              # a gather kernel on THIS rank's GPU reads rank 0's pages
+                            good = good if got == [sig + p for p in ids] + [sig - p for p in ids] else 0.0
+                    elif rank != 0:
+                        good = 1.0 if seen and seen[-1] == (k, k * (1 if units == "page_ids" else 2 * L)) else 0.0
+                    t3 = time.perf_counter()
+                    ok_all = ok_all and red(good, dist.ReduceOp.MIN) == 1.0
+                    if rank != 0:
+                        capi.unmap_from_kv_tensors(offs)                      # the imports are dropped first ...
+                    dist.barrier()
+                    if rank == 0:
+                        capi.unmap_from_kv_tensors(offs)                      # ... then the owner gives the pages back
+                    if it:                                                    # (the first round warms sockets and pools)
+                        back.append(t1 - t0)
+                        share.append(red(t2 - t1, dist.ReduceOp.MAX))
+                        verify.append(red(t3 - t2, dist.ReduceOp.MAX))
+                res[f"{k}_page_ids"] = {"slots_2MiB": k * 2 * L, "descriptors": (("one per buffer: at most " if not rehearsal else "") + str(k)) if units == "page_ids" else k * 2 * L,
+                                        "rank0_back_ms_p50": med(back), "export_ship_import_map_ms_p50_slowest_rank": med(share),
+                                        "ms_per_page_id": round(statistics.median(share) * 1e3 / k, 3),
+                                        "us_per_slot_per_peer": round(statistics.median(share) * 1e6 / (k * 2 * L) / max(1, world - 1), 2),
+                                        "peers_read_rank0_signature_ms_p50": med(verify), "signature_seen_by_every_peer": ok_all}
+            # which way the peers' imports went (each rank reports its own counters; rank 0 imports nothing)
+            mine = torch.tensor([float(capi.get_option(163) - imp0[0]), float(capi.get_option(164) - imp0[1])], dtype=torch.float64, device=cdev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            res["imports_by_rank"] = [{"rank": r, "straight_into_KFD_and_DRM": int(e[0]), "through_the_runtime_ROCr": int(e[1])} for r, e in enumerate(every)]
+            chan.close()
+        except Exception as e:   # (a rank that fails here takes the others with it through the collectives' timeouts: the mode is reported as failed)
+            res["error"] = f"{type(e).__name__}: {str(e)[:300]}"
+        finally:
+            vmm_ops.shutdown_kvcached()
+            os.environ.pop("KVCACHED_EXPORTABLE_HANDLES", None)
+        out["page_ids_as_units" if units == "page_ids" else "slot_by_slot"] = res
+    gpus = torch.tensor([float(torch.cuda.current_device()) if not rehearsal else -1.0], dtype=torch.float64, device=cdev)
+    seen_gpus = [torch.zeros_like(gpus) for _ in range(world)]
+    dist.all_gather(seen_gpus, gpus)
+    distinct = len({int(g.item()) for g in seen_gpus})
+    out["gpus_used"] = distinct if not rehearsal else 0
+    out["what"] = ("cross-GPU: rank 0's pages are read by the peers over xGMI" if distinct == world and not rehearsal else
+                   "REHEARSAL on the library's cpu device: offsets and file descriptors travel, nothing is mapped" if rehearsal else
+                   f"REHEARSAL: {world} ranks share {distinct} GPU(s) - the export/ship/import/map machinery runs end to end, but nothing crosses xGMI")
     return out
 
 
@@ -576,6 +588,36 @@ def run_shared_pool_child(args):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def shared_pool_rehearsal_on_one_gpu():
+    """N = 1 has no peers: the leg is REHEARSED with two child ranks that share this GPU (gloo for the collective - RCCL refuses two
+    ranks on one device), so that the driver's single-GPU record shows the export / SCM_RIGHTS / import / map machinery running and the
+    peers reading rank 0's signature on this very box. Labelled as a rehearsal in the result; nothing crosses xGMI."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   KVC_BENCH_BACKEND="gloo", KVC_BENCH_SHARE_GPUS="1", KVCACHED_IPC_NAME=f"kvc_bench_share_{port}")
+        env.pop("KVC_BENCH_FORCE_DIST", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--shared-pool-leg"], env=env, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    try:
+        out, err = procs[0].communicate(timeout=180)
+        for p in procs[1:]:
+            p.wait(timeout=60)
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return {"error": "the one-GPU rehearsal of the shared-pool leg did not finish within 180 s"}
+    js = [l for l in out.splitlines() if l.startswith("{")]
+    if procs[0].returncode != 0 or not js:
+        return {"error": f"rank 0 of the rehearsal exited with status {procs[0].returncode}", "stderr_tail": (err or out)[-400:]}
+    return json.loads(js[-1])
 
 
 def shared_pool_in_children(rank, world):
@@ -820,8 +862,9 @@ def main():
         if shared is not None:
             line["shared_pool"] = shared
             for k in (1, 8):
-                if isinstance(shared.get(f"{k}_page_ids"), dict):
-                    line["config"][f"shared_pool_{k}_page_ids_ms"] = shared[f"{k}_page_ids"]["export_ship_import_map_ms_p50_slowest_rank"]
+                leg = (shared.get("page_ids_as_units") or {}).get(f"{k}_page_ids")
+                if isinstance(leg, dict):
+                    line["config"][f"shared_pool_{k}_page_ids_ms"] = leg["export_ship_import_map_ms_p50_slowest_rank"]
         if world == 1 and not rehearsal:
             if first_touch is not None:
                 line["growth_burst_first_touch"] = first_touch
@@ -902,6 +945,10 @@ def main():
                     line["roofline_compact_blocks"] = compaction_roofline(capi, device)
                 except Exception as e:
                     line["roofline_compact_blocks"] = {"error": str(e)[:200]}
+                try:   # BASELINE config 4 on one GPU: a rehearsal (two ranks share the device), so that the machinery has run on this box
+                    line["shared_pool"] = shared_pool_rehearsal_on_one_gpu()
+                except Exception as e:
+                    line["shared_pool"] = {"error": str(e)[:200]}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
                 line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)

@@ -295,6 +295,17 @@ int64_t kvc_unique_block_ids(const int64_t *token_indices_dev, size_t n, int64_t
  * the fds (received over SCM_RIGHTS) and map them at the same offsets. */
 int kvc_export_mapped_slots(const int64_t *offsets, size_t n, int64_t group_id, int *out_fds, int64_t cap); /* returns fd count */
 int kvc_map_imported_slots(const int64_t *offsets, size_t n, int64_t group_id, const int *fds, size_t n_fds);
+/* The same with page ids as units (multi-row geometries whose page ids are backed by lanes: kvc_get_option(129) > 0). ONE dmabuf fd
+ * per BUFFER - up to 8 page ids live in one, their lanes side by side - instead of one per 2 MiB slot (64 per page id for
+ * Llama-3-8B), and three numbers per page id that tell the peer where its pages are: meta[3i] = which of the exported fds,
+ * meta[3i+1] = lanes that buffer holds (k), meta[3i+2] = the lane that is page id i's (j); the page behind row r is at byte
+ * (r * k + j) * page_size of the buffer. kvc_export_page_ids returns the number of fds written (<= n; with cap < n: n, nothing
+ * exported); KVC_E_INVALID if one of the page ids is not backed by a lane of this process (then export slot by slot).
+ * kvc_map_imported_page_ids imports every fd once and maps the page ids at the same offsets - every row of every page id must
+ * be unbacked; page ids that are neighbours in one buffer are one ioctl per row - and owns the imported buffers from then on (each
+ * is released when the last page id it backs is unmapped, after the TLB invalidation that imports always get inside the call). */
+int kvc_export_page_ids(const int64_t *offsets, size_t n, int64_t group_id, int *out_fds, int64_t *out_meta, int64_t cap);
+int kvc_map_imported_page_ids(const int64_t *offsets, size_t n, int64_t group_id, const int *fds, size_t n_fds, const int64_t *meta);
 
 #ifdef __cplusplus
 }

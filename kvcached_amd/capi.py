@@ -135,6 +135,8 @@ SIGNATURES = {
     "kvc_unique_block_ids": (_i64, [_vp, _sz, _i64, _i64, _I64P, _sz, _vp]),
     "kvc_export_mapped_slots": (_int, [_I64P, _sz, _i64, _INTP, _i64]),
     "kvc_map_imported_slots": (_int, [_I64P, _sz, _i64, _INTP, _sz]),
+    "kvc_export_page_ids": (_int, [_I64P, _sz, _i64, _INTP, _I64P, _i64]),
+    "kvc_map_imported_page_ids": (_int, [_I64P, _sz, _i64, _INTP, _sz, _I64P]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not match the header
@@ -309,3 +311,19 @@ def export_mapped_slots(offsets: Sequence[int], group_id: int = 0) -> List[int]:
 def map_imported_slots(offsets: Sequence[int], fds: Sequence[int], group_id: int = 0) -> None:
     arr = (ctypes.c_int * max(1, len(fds)))(*fds)
     check(lib.kvc_map_imported_slots(i64_array(offsets), len(offsets), group_id, arr, len(fds)))
+
+
+def export_page_ids(offsets: Sequence[int], group_id: int = 0) -> Tuple[List[int], List[int]]:
+    """Shared pool with page ids as units: one dmabuf fd per BUFFER (up to 8 page ids live in one) and, per page id, (which fd, lanes
+    in that buffer, lane index). Raises KvcError(KVC_E_INVALID) if the page ids are not backed by lanes of this process."""
+    n = len(offsets)
+    fds, meta = (ctypes.c_int * max(1, n))(), (ctypes.c_int64 * max(1, 3 * n))()
+    k = check(lib.kvc_export_page_ids(i64_array(offsets), n, group_id, fds, meta, n))
+    return [int(fds[i]) for i in range(k)], [int(meta[i]) for i in range(3 * n)]
+
+
+def map_imported_page_ids(offsets: Sequence[int], fds: Sequence[int], meta: Sequence[int], group_id: int = 0) -> None:
+    if len(meta) != 3 * len(offsets):
+        raise ValueError("one (fd index, lanes, lane) triple per page id")
+    arr = (ctypes.c_int * max(1, len(fds)))(*fds)
+    check(lib.kvc_map_imported_page_ids(i64_array(offsets), len(offsets), group_id, arr, len(fds), i64_array(meta)))

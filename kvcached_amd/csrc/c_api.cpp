@@ -543,5 +543,14 @@ int kvc_map_imported_slots(const int64_t *offsets, size_t n, int64_t group_id, c
                                                                                       : fail(KVC_E_NOT_CREATED, "KV tensors are not created");
   });
 }
+int kvc_export_page_ids(const int64_t *offsets, size_t n, int64_t group_id, int *out_fds, int64_t *out_meta, int64_t cap) {
+  return guarded([&]() -> int { return KvAllocator::global(group_id)->export_page_ids(offsets, n, out_fds, out_meta, cap); });
+}
+int kvc_map_imported_page_ids(const int64_t *offsets, size_t n, int64_t group_id, const int *fds, size_t n_fds, const int64_t *meta) {
+  return guarded([&]() -> int {
+    return KvAllocator::global(group_id)->map_imported_page_ids(offsets, n, fds, n_fds, meta) ? KVC_OK
+                                                                                          : fail(KVC_E_NOT_CREATED, "KV tensors are not created");
+  });
+}
 
 } // extern "C"

@@ -512,10 +512,12 @@ KvAllocator::~KvAllocator() {
   std::lock_guard<std::mutex> g(mu_);
   size_t still_queued = 0;
   std::vector<Phys> lanes; // page ids still backed by lanes: their pages go home once every row is unmapped
-  if (lanes_ && !rows_.empty())
+  std::vector<phys_handle_t> peers_buffers; // ... and buffers of a peer that back page ids here: released once each
+  if (!rows_.empty())
     for (size_t p = 0; p < ids_per_row_; ++p) {
       const size_t idx = rows_[0].first + p;
       if (rows_[0].r->mapped[idx] == 4) lanes.push_back(Phys{rows_[0].r->handle[idx], rows_[0].r->seq[idx]});
+      if (rows_[0].r->mapped[idx] == 5) peers_buffers.push_back(rows_[0].r->handle[idx]);
     }
   for (auto &r : layers_) {
     for (auto m : r->mapped) still_queued += (m == 3) ? r->page_size : 0;
@@ -532,6 +534,10 @@ KvAllocator::~KvAllocator() {
     if (!lanes.empty()) lane_pool_->release_batch(lanes.data(), lanes.size());
     lane_pool_->drain(0); // an allocator that goes away gives its memory back (the reference releases in ~FTensor, ftensor.cpp:78-98)
   }
+  std::sort(peers_buffers.begin(), peers_buffers.end());
+  peers_buffers.erase(std::unique(peers_buffers.begin(), peers_buffers.end()), peers_buffers.end());
+  for (auto h : peers_buffers) (void)vmm_try_release(h);
+  peer_refs_.clear();
 }
 
 // ------------------------------------------------------------------ async unmap
@@ -905,7 +911,7 @@ void KvAllocator::destroy_region(KvRegion &r) {
     if (!whole) {
       if (!vmm_try_unmap(r.base + i * r.page_size, r.page_size, r.handle[i])) KVC_LOG(LOG_ERROR, "unmap during cleanup failed (slot %zu)", i);
     }
-    if (r.mapped[i] != 4) // (4: a page of a lane - the lane goes home once, from ~KvAllocator, not once per row)
+    if (r.mapped[i] != 4 && r.mapped[i] != 5) // (4 / 5: a page of a lane / of a peer's lane - released once, from ~KvAllocator, not once per row)
       (r.mapped[i] != 2 ? pieces : dead).push_back(Phys{r.handle[i], r.seq[i]});
     r.mapped[i] = 0;
   }
@@ -1979,7 +1985,8 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
   for (size_t i = 0; i < n; ++i) {
     const offset_t off = offsets[i];
     const bool valid = off >= 0 && (size_t)off % ps == 0 && (size_t)off / ps < ids_per_row_;
-    if (valid && rows_[0].r->mapped[rows_[0].first + (size_t)off / ps] == 4) {
+    const uint8_t state = valid ? rows_[0].r->mapped[rows_[0].first + (size_t)off / ps] : 0;
+    if (state == 4 || state == 5) {
       if (!scan.add(rows_[0].r, rows_[0].first + (size_t)off / ps)) KVC_LOG(LOG_ERROR, "Page %zu is not mapped.", (size_t)off / ps); // named twice
     } else {
       others->push_back(off);
@@ -1992,6 +1999,7 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
   const std::vector<SlotRun> runs = scan.collect();
   sg.mark(11);
   std::vector<Phys> lanes;
+  std::vector<phys_handle_t> peers_buffers; // page ids that were backed by a peer's lane: its buffer is released once, after the invalidation
   KeyGroups<uint32_t> touched(n); // buffer -> lanes of it that this call takes back
   bool any_backfilled = false;
   for (const SlotRun &run : runs) {
@@ -2015,6 +2023,10 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
     for (size_t p = p0; p < p0 + run.count; ++p) {
       const size_t idx0 = rows_[0].first + p;
       const phys_handle_t h = rows_[0].r->handle[idx0];
+      if (rows_[0].r->mapped[idx0] == 5) {
+        peers_buffers.push_back(h);
+        continue;
+      }
       lanes.push_back(Phys{h, rows_[0].r->seq[idx0]});
       ++touched.at(chunk_of(h));
     }
@@ -2048,8 +2060,22 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
     }
   sg.mark(15);
   // the invalidation: inside the call where unbacked VA promises zeros (compat), behind it otherwise (see unmap_finish)
+  const size_t n_ids = lanes.size() + peers_buffers.size();
+  if (!peers_buffers.empty()) { // a peer's memory: no translation of it may survive the call
+    ctx->ensure_flushed();
+    for (auto h : peers_buffers) { // (one entry per page id: the buffer goes when the last page id it backs here has gone)
+      auto it = peer_refs_.find(h);
+      if (it != peer_refs_.end() && --it->second > 0) continue;
+      if (it != peer_refs_.end()) peer_refs_.erase(it);
+      if (!vmm_try_release(h)) KVC_LOG(LOG_ERROR, "releasing an imported buffer failed");
+    }
+    if (lanes.empty()) {
+      stats().pages_unmapped += (int64_t)(n_ids * R);
+      return n_ids;
+    }
+  }
   const int64_t trail_us = options().deferred_unmap_flush_us.load();
-  if (trail_us > 0 && any_backfilled) { // compat, relaxed: see unmap_finish
+  if (trail_us > 0 && any_backfilled && peers_buffers.empty()) { // compat, relaxed: see unmap_finish
     auto own = std::make_shared<std::vector<Phys>>(std::move(lanes));
     ctx->park(epoch, own->size() * R * ps, [ctx, pool, own, R, ps]() {
       uint64_t ticket = 0;
@@ -2095,8 +2121,8 @@ size_t KvAllocator::unmap_lanes(const offset_t *offsets, size_t n, std::vector<o
   pool->release_batch(lanes.data(), lanes.size(), ticket);
   sg.mark(18);
   stats().t_release += now_ns() - tr0;
-  stats().pages_unmapped += (int64_t)(lanes.size() * R);
-  return lanes.size();
+  stats().pages_unmapped += (int64_t)(n_ids * R);
+  return n_ids;
 }
 
 // ------------------------------------------------------------------ TP shared pool
@@ -2181,6 +2207,166 @@ int KvAllocator::export_mapped_slots(const offset_t *offsets, size_t n, int *out
     throw;
   }
   return k;
+}
+
+int KvAllocator::export_page_ids(const offset_t *offsets, size_t n, int *out_fds, int64_t *out_meta, int64_t cap) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!dev_.is_gpu) throw NoGpuError("export_page_ids needs a GPU device");
+  if (!lanes_) throw InvalidError("page ids are not backed as units here (kvc_get_option(129) == 0): export slot by slot");
+  if ((int64_t)n > cap) return (int)n;
+  const size_t ps = rows_[0].r->page_size;
+  for (size_t i = 0; i < n; ++i) { // nothing is exported unless everything can be
+    const offset_t off = offsets[i];
+    if (off < 0 || (size_t)off % ps != 0 || (size_t)off / ps >= ids_per_row_ || rows_[0].r->mapped[rows_[0].first + (size_t)off / ps] != 4)
+      throw InvalidError("export of a page id that is not backed by a lane of this process");
+  }
+  ctx_->bind();
+  KeyGroups<int> bufs(n); // buffer -> its place among the exported fds (order of first appearance)
+  int k = 0;
+  try {
+    for (size_t i = 0; i < n; ++i) {
+      const phys_handle_t h = rows_[0].r->handle[rows_[0].first + (size_t)offsets[i] / ps];
+      const size_t before = bufs.items().size();
+      int &at = bufs.at(chunk_of(h));
+      if (bufs.items().size() != before) { // first page id of this buffer: export it (AMDKFD_IOC_EXPORT_DMABUF)
+        const int fd = DrmVm::instance().export_fd(chunk_of(h));
+        if (fd < 0) throw GpuError("a lane's buffer cannot be exported");
+        out_fds[k] = fd;
+        at = k++;
+      }
+      out_meta[3 * i] = at;
+      out_meta[3 * i + 1] = (int64_t)pages_of(h);
+      out_meta[3 * i + 2] = (int64_t)piece_of(h);
+    }
+  } catch (...) {
+    for (int i = 0; i < k; ++i) ::close(out_fds[i]);
+    throw;
+  }
+  return k;
+}
+
+bool KvAllocator::map_imported_page_ids(const offset_t *offsets, size_t n, const int *fds, size_t n_fds, const int64_t *meta) {
+  std::lock_guard<std::mutex> g(mu_);
+  if (!dev_.is_gpu) throw NoGpuError("map_imported_page_ids needs a GPU device");
+  if (num_layers_ == 0) return false;
+  if (rows_.empty()) throw InvalidError("page ids cannot be imported as units here (single-row geometry or not the drm backend): import slot by slot");
+  if (!n) return true;
+  const size_t R = rows_.size(), ps = rows_[0].r->page_size;
+  struct Id {
+    size_t p;
+    uint64_t buf, k, j;
+  };
+  std::vector<Id> ids(n);
+  for (size_t i = 0; i < n; ++i) {
+    const offset_t off = offsets[i];
+    if (off < 0 || (size_t)off % ps != 0 || (size_t)off / ps >= ids_per_row_) throw InvalidError("offset " + std::to_string(off) + " is not a page id of this geometry");
+    const int64_t b = meta[3 * i], k = meta[3 * i + 1], j = meta[3 * i + 2];
+    if (b < 0 || (size_t)b >= n_fds || k < 1 || k > (int64_t)kMaxExtentPages || j < 0 || j >= k)
+      throw InvalidError("import of a page id: (fd " + std::to_string(b) + ", lane " + std::to_string(j) + " of " + std::to_string(k) + ") names no lane of the buffers that came along");
+    ids[i] = Id{(size_t)off / ps, (uint64_t)b, (uint64_t)k, (uint64_t)j};
+    for (const Row &row : rows_)
+      if (row.r->mapped[row.first + ids[i].p] != 0) throw InvalidError("import into a page id that is backed already");
+  }
+  std::sort(ids.begin(), ids.end(), [](const Id &a, const Id &b) { return a.p < b.p; });
+  for (size_t i = 1; i < n; ++i)
+    if (ids[i].p == ids[i - 1].p) throw InvalidError("import of a page id that is named twice");
+  GpuContext *ctx = ctx_;
+  ctx->bind();
+  DrmVm &vm = DrmVm::instance();
+  if (!vm.kfd_ready()) throw InvalidError("importing page ids as units needs the drm backend with pages straight from KFD");
+  std::vector<phys_handle_t> bufs(n_fds, 0);
+  struct Done {
+    size_t p, cnt, rows_done;
+    phys_handle_t h;
+    bool settled;
+  };
+  std::vector<Done> done;
+  bool prt_dirty = false, replaced = false;
+  void *zx_dirty = nullptr;
+  uint64_t need_epoch = 0;
+  try {
+    for (size_t f = 0; f < n_fds; ++f) { // AMDKFD_IOC_IMPORT_DMABUF + DRM import, once per buffer
+      bufs[f] = vm.import_fd(fds[f]);
+      ++g_imports_direct;
+    }
+    for (size_t i = 0; i < n;) {
+      size_t cnt = 1; // page ids that are neighbours here AND in one buffer: one ioctl per row
+      while (i + cnt < n && ids[i + cnt].p == ids[i].p + cnt && ids[i + cnt].buf == ids[i].buf && ids[i + cnt].k == ids[i].k &&
+             ids[i + cnt].j == ids[i].j + cnt)
+        ++cnt;
+      const Id &first = ids[i];
+      done.push_back(Done{first.p, cnt, 0, bufs[first.buf], false});
+      Done &d = done.back();
+      void *bo = vm.find(d.h);
+      if (!bo) throw GpuError("an imported buffer is not a direct DRM buffer");
+      for (size_t r = 0; r < R; ++r) {
+        KvRegion &reg = *rows_[r].r;
+        const size_t idx = rows_[r].first + first.p;
+        for (size_t c = 0; c < cnt; ++c) {
+          if (vmm_hip_registered() && !reg.registered[idx + c]) register_slot(reg, idx + c);
+          need_epoch = std::max(need_epoch, reg.stale_epoch[idx + c]);
+        }
+        char *va = reg.base + idx * ps;
+        const uint64_t boff = (r * first.k + first.j) * ps;
+        int rc;
+        if (reg.rest_direct()) {
+          tlb_stale().store(true);
+          rc = vm.replace(bo, va, cnt * ps, boff);
+          tlb_stale().store(true);
+          replaced = true;
+          if (reg.zx) zx_dirty = vm.find(reg.zx_handle);
+          if (reg.prt) prt_dirty = true;
+        } else {
+          rc = vm.map(bo, va, cnt * ps, boff);
+        }
+        if (rc != 0) throw GpuError(std::string("DRM_AMDGPU_GEM_VA (mapping a peer's page ids) failed: ") + strerror(rc < 0 ? -rc : rc) +
+                                    " - does the buffer hold " + std::to_string(first.k) + " lanes of " + std::to_string(R) + " pages?");
+        d.rows_done = r + 1;
+      }
+      for (const Row &row : rows_)
+        for (size_t c = 0; c < cnt; ++c) {
+          row.r->handle[row.first + first.p + c] = d.h;
+          row.r->seq[row.first + first.p + c] = 0;
+          row.r->mapped[row.first + first.p + c] = 5;
+        }
+      d.settled = true;
+      stats().seg[21] += (int64_t)R;
+      i += cnt;
+    }
+    if (prt_dirty && !vm.refresh_prt_remainders()) throw GpuError("rewriting the remainders of split PRT mappings failed");
+    if (zx_dirty && !vm.refresh_mappings_of(zx_dirty, ps)) KVC_LOG(LOG_ERROR, "rewriting the remaining mappings of the zero extent failed");
+    if (replaced) {
+      tlb_stale().store(true);
+      need_epoch = ctx->next_flush_epoch();
+    }
+    ctx->ensure_flushed_through(need_epoch);
+  } catch (...) {
+    for (auto it = done.rbegin(); it != done.rend(); ++it) {
+      for (size_t r = 0; r < it->rows_done; ++r) {
+        KvRegion &reg = *rows_[r].r;
+        if (reg.rest_direct())
+          for_rest_pieces(reg, rows_[r].first + it->p, it->cnt, [&](size_t f0, size_t c) { (void)rest_replace(reg, f0, c); });
+        else
+          (void)vm.clear(reg.base + (rows_[r].first + it->p) * ps, it->cnt * ps);
+      }
+      if (it->settled)
+        for (const Row &row : rows_)
+          for (size_t c = 0; c < it->cnt; ++c) row.r->mapped[row.first + it->p + c] = 0;
+    }
+    (void)hipGetLastError();
+    try {
+      ctx->tlb_shootdown();
+    } catch (...) {
+    }
+    for (auto h : bufs)
+      if (h) (void)vmm_try_release(h);
+    throw;
+  }
+  for (const Id &id : ids) ++peer_refs_[bufs[id.buf]];
+  for (auto h : bufs) // (an fd that came along but backs none of the page ids)
+    if (h && !peer_refs_.count(h)) (void)vmm_try_release(h);
+  stats().pages_mapped += (int64_t)(n * R);
+  return true;
 }
 
 bool KvAllocator::map_imported_slots(const offset_t *offsets, size_t n, const int *fds, size_t n_fds) {

@@ -309,7 +309,8 @@ struct KvRegion {
   std::vector<uint64_t> mark;          // one bit per slot, all clear at rest: scratch of RunScan (kv_allocator.cpp), under the allocator's lock
   std::vector<uint8_t> mapped;         // per slot: 0 = unbacked, 1 = backed by its own page, 2 = by an imported page,
                                        // 3 = released by the caller, physical unmap still queued (async unmap),
-                                       // 4 = backed by a page of a LANE (handle = the lane's: one per page id, shared by all its rows)
+                                       // 4 = backed by a page of a LANE (handle = the lane's: one per page id, shared by all its rows),
+                                       // 5 = by a page of a peer's lane (handle = the imported buffer's, shared by all rows of the page id)
   size_t num_slots() const { return size / page_size; }
 };
 
@@ -351,6 +352,9 @@ public:
   // TP shared pool
   int export_mapped_slots(const offset_t *offsets, size_t n, int *out_fds, int64_t cap);
   bool map_imported_slots(const offset_t *offsets, size_t n, const int *fds, size_t n_fds);
+  // ... with page ids as units (lanes): one fd per page id + (lanes in the buffer, lane index) per page id
+  int export_page_ids(const offset_t *offsets, size_t n, int *out_fds, int64_t *out_meta, int64_t cap);
+  bool map_imported_page_ids(const offset_t *offsets, size_t n, const int *fds, size_t n_fds, const int64_t *meta);
 
 private:
   struct Slot {
@@ -409,6 +413,7 @@ private:
   std::vector<Row> rows_;        // layer-major, K then V: the order slots_for() lists the slots of one offset in
   size_t ids_per_row_ = 0;       // page ids a row has room for
   ExtentPool *lane_pool_ = nullptr;
+  std::unordered_map<phys_handle_t, uint32_t> peer_refs_; // imported buffers -> page ids of ours they back (released at 0)
   bool reserve_built_ = false;   // the cold-start instalments of the reserve are over (cold_start_reserve)
   // async unmap state (guarded by mu_)
   std::deque<Slot> pending_;

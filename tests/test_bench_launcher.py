@@ -38,11 +38,13 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     sp = line["shared_pool"]
     assert "error" not in sp, sp
     assert sp["ranks"] == 2 and sp["rccl_world_size"] == 2 and "REHEARSAL" in sp["what"]
-    for k in (1, 8):
-        leg = sp[f"{k}_page_ids"]
-        assert leg["slots_2MiB"] == k * 64 and leg["signature_seen_by_every_peer"] is True
-        assert leg["export_ship_import_map_ms_p50_slowest_rank"] > 0
-    assert line["config"]["shared_pool_8_page_ids_ms"] == sp["8_page_ids"]["export_ship_import_map_ms_p50_slowest_rank"]
+    for mode, per in (("page_ids_as_units", 1), ("slot_by_slot", 64)):   # one descriptor per page id, or one per 2 MiB slot
+        assert "error" not in sp[mode], sp[mode]
+        for k in (1, 8):
+            leg = sp[mode][f"{k}_page_ids"]
+            assert leg["slots_2MiB"] == k * 64 and str(leg["descriptors"]) == str(k * per) and leg["signature_seen_by_every_peer"] is True
+            assert leg["export_ship_import_map_ms_p50_slowest_rank"] > 0
+    assert line["config"]["shared_pool_8_page_ids_ms"] == sp["page_ids_as_units"]["8_page_ids"]["export_ship_import_map_ms_p50_slowest_rank"]
     assert line["rccl_world_size"] == 2
 
 

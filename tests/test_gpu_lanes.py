@@ -317,3 +317,58 @@ def test_whole_tensors_can_be_read_next_to_background_mapping(lanes, monkeypatch
     assert sweeps > 20 and rounds[0] > 100, (sweeps, rounds)
     with pytest.raises(RuntimeError):
         capi.check(capi.lib.kvc_quiesce_end())                                     # an end without a begin is refused
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_page_ids_are_shared_as_units(lanes, compat):
+    """The shared pool with page ids as units (north star: rank 0 creates, peers map; no reference counterpart): ONE dmabuf per page
+    id - the buffer its lane lives in - plus (lanes in the buffer, lane index); the importer maps row r at (r x lanes + lane) x page.
+    Page ids that are neighbours in one buffer travel as ONE descriptor and are one ioctl per row on the importing side.
+    Here the "peer" is a second group of the same process: both groups see the same bytes in every row; an unmap on the importing
+    side drops the import (and, compat, reads zero again) without touching the owner's page; the owner's memory goes home once."""
+    from kvcached_amd import capi, vmm_ops as ops
+    os.environ["KVCACHED_ZERO_BACKFILL"] = "true" if compat else "false"
+    ops.init_kvcached(DEV, PAGE, False)
+    layers, half = 3, 32
+    a = ops.create_kv_tensors(2 * half * PAGE, 2, DEV, layers, 2, 0, False)
+    b = ops.create_kv_tensors(2 * half * PAGE, 2, DEV, layers, 2, 1, False)        # group 1 = the "peer"
+    rows = lambda ts: [v for t in ts for v in (t[:half * EPP].view(half, EPP), t[half * EPP:].view(half, EPP))]   # noqa: E731
+    va, vb = rows(a), rows(b)
+    R = len(va)
+    capi.reset_stats()
+    ids = [4, 5, 6, 20]                                                # a run of three (one buffer, three lanes) and a single one
+    assert ops.map_to_kv_tensors([p * PAGE for p in ids], 0)
+    _stamp(va, ids, 4000)
+    fds, meta = capi.export_page_ids([p * PAGE for p in ids], 0)
+    # two buffers: the run of three (three lanes, in order) and the single one
+    assert len(fds) == 2 and meta == [0, 3, 0, 0, 3, 1, 0, 3, 2, 1, 1, 0], meta
+    i0 = capi.get_option(130 + 21)
+    m0 = capi.get_stats()["pages_mapped"]
+    capi.map_imported_page_ids([p * PAGE for p in ids], fds, meta, 1)
+    for fd in fds:
+        os.close(fd)
+    assert capi.get_stats()["pages_mapped"] - m0 == 4 * R and capi.get_option(130 + 21) - i0 == 2 * R   # one ioctl per row per run of neighbours
+    _check(vb, ids, 4000)                                              # the peer sees the owner's bytes, row by row, page id by page id
+    vb[R - 1][5][100:116] = 77                                         # ... and writes into the same memory
+    torch.cuda.synchronize()
+    assert bool((va[R - 1][5][100:116] == 77).all())
+    with pytest.raises(RuntimeError):                                  # a page id that is backed already cannot take an import
+        f2, m2 = capi.export_page_ids([4 * PAGE], 0)
+        try:
+            capi.map_imported_page_ids([4 * PAGE], f2, m2, 1)
+        finally:
+            for fd in f2:
+                os.close(fd)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in (5, 20)], 1)   # the peer lets two of them go
+    if compat:
+        for v in vb:
+            assert int(torch.count_nonzero(v[5][::64])) == 0 and int(torch.count_nonzero(v[20][::64])) == 0
+    _check(va, [4, 6, 20], 4000)                                       # the owner's pages are untouched
+    _check(vb, [4, 6], 4000)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in (4, 6)], 1)
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in ids], 0)
+    with pytest.raises(RuntimeError):                                  # nothing to export any more
+        capi.export_page_ids([4 * PAGE], 0)
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]

@@ -33,7 +33,7 @@ def _rank(rank, world, port, ipc, q):
             made.append(len(fds))
             return fds
 
-        def importer(offs, fds, gid):
+        def importer(offs, fds, gid, meta):
             if gid == 7 and rank == 2:
                 raise RuntimeError("import refused [injected]")
             got.append((list(offs), [os.pread(fd, 64, 0).decode() for fd in fds], gid))
