@@ -214,11 +214,14 @@ def _serve_connection(rank: int, conn: socket.socket) -> None:
             except (ConnectionError, OSError):
                 return
             try:
-                if msg.get("cmd") == "map_imported_slots":  # shared-pool: fds follow as SCM_RIGHTS
+                if msg.get("cmd") in ("map_imported_slots", "map_imported_page_ids"):  # shared-pool: fds follow as SCM_RIGHTS
                     from kvcached_amd import capi
                     _, fds = recv_fds(conn, msg["n_fds"])
                     try:
-                        capi.map_imported_slots(msg["offsets"], fds, msg.get("group_id", 0))
+                        if msg["cmd"] == "map_imported_page_ids":   # one dmabuf per buffer of lanes + (fd index, lanes, lane) per page id
+                            capi.map_imported_page_ids(msg["offsets"], fds, msg["meta"], msg.get("group_id", 0))
+                        else:
+                            capi.map_imported_slots(msg["offsets"], fds, msg.get("group_id", 0))
                     finally:
                         for fd in fds:
                             os.close(fd)
@@ -367,9 +370,20 @@ def share_mapped_slots(tp_size: int, offsets: List[int], pp_rank: int = 0, group
     """Shared-pool mode: the calling process (rank `src_rank`, which has just backed `offsets`
     with exportable handles) exports them and every other rank maps the same physical pages."""
     from kvcached_amd import capi
-    fds = capi.export_mapped_slots(offsets, group_id)
+    # page ids as units where the library backs them as lanes (one dmabuf per buffer: DESIGN.md §4.11), slot by slot otherwise
+    # (single-row geometries, other backends, KVCACHED_EXPORTABLE_HANDLES=1)
+    meta = None
+    if capi.get_option(129) > 0:
+        try:
+            fds, meta = capi.export_page_ids(offsets, group_id)
+        except capi.KvcError:
+            meta = None
+    if meta is None:
+        fds = capi.export_mapped_slots(offsets, group_id)
     try:
         msg = {"cmd": "map_imported_slots", "offsets": list(offsets), "group_id": group_id, "n_fds": len(fds)}
+        if meta is not None:
+            msg.update(cmd="map_imported_page_ids", meta=meta)
         with _channels._lock:
             peers = [(r, pp_rank) for r in range(tp_size) if r != src_rank]
             sent, failure = [], None

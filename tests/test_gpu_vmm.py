@@ -1230,14 +1230,17 @@ def _peer_process(sock_path, ipc, q):
         q.put(("ERR", repr(e)))
 
 
-def test_shared_pool_between_two_processes(vmm):
-    """north-star TP sharing: rank 0 backs a page id with exportable handles, exports one POSIX fd per slot
-    (hipMemExportToShareableHandle), ships them with SCM_RIGHTS over the worker's Unix socket; the peer
-    imports (hipMemImportFromShareableHandle) and maps them at the same offsets. Both see the same bytes."""
+@pytest.mark.parametrize("units", ["slots", "page_ids"])
+def test_shared_pool_between_two_processes(vmm, units):
+    """north-star TP sharing: rank 0 backs a page id, exports it - slot by slot (exportable handles, one POSIX fd per slot:
+    hipMemExportToShareableHandle / AMDKFD_IOC_EXPORT_DMABUF) or, where page ids are backed as lanes, ONE dmabuf for the buffer the
+    page id lives in - and ships the descriptors with SCM_RIGHTS over the worker's Unix socket; the peer imports and maps at the
+    same offsets. Both see the same bytes."""
     import multiprocessing as mp
     ops, capi = vmm["ops"], vmm["capi"]
     ipc = os.environ["KVCACHED_IPC_NAME"]
-    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    if units == "slots":
+        os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     from kvcached_amd import tp_ipc_util as tp
@@ -1246,8 +1249,10 @@ def test_shared_pool_between_two_processes(vmm):
         peer.start()
         ops.init_kvcached(DEV, PAGE, False)
         ts = ops.create_kv_tensors(16 * MiB, 2, DEV, 2, 2, 0, False)
+        assert (capi.get_option(129) > 0) == (units == "page_ids")
         msg = q.get(timeout=180)
         assert msg == "ready", msg
+        i0 = capi.get_option(163)
         assert ops.map_to_kv_tensors([PAGE])
         epp = PAGE // 2
         k = 0
