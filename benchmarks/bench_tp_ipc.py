@@ -53,7 +53,8 @@ def worker(rank: int, n_gpus: int, layers: int, per_layer: int, ipc: str, ready,
 def shared_pool(args):
     ipc = f"kvc_tpshare_{os.getpid()}"
     os.environ["KVCACHED_IPC_NAME"] = ipc
-    os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
+    if args.units == "slots":            # one dmabuf per 2 MiB slot (exportable single pages); "page_ids": one per buffer of lanes
+        os.environ["KVCACHED_EXPORTABLE_HANDLES"] = "1"
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
     import torch
     n_gpus = torch.cuda.device_count()
@@ -74,7 +75,7 @@ def shared_pool(args):
             ready.get(timeout=180)
         tp_size = W + 1
         assert tp.broadcast_kv_tensors_created(tp_size)
-        res = {"mode": "shared pool: rank 0 backs + exports, peers import + map the same pages", "peers": W,
+        res = {"mode": "shared pool: rank 0 backs + exports, peers import + map the same pages", "units": args.units, "peers": W,
                "gpus_visible": n_gpus, "layers": args.layers}
         for n in (1, 8):
             t_back, t_share, t_unmap = [], [], []
@@ -108,6 +109,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--shared-pool", action="store_true")
+    ap.add_argument("--units", choices=["page_ids", "slots"], default="page_ids", help="--shared-pool: what a descriptor stands for")
     args = ap.parse_args()
     if args.shared_pool:
         args.workers = args.workers or "1,3"

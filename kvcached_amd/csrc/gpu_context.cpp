@@ -309,7 +309,8 @@ void GpuContext::housekeeping() {
   const int64_t idle_ms = options().pool_idle_ms.load();
   // the reserve never exceeds the pool's cap (KVCACHED_PHYS_POOL_MB=0, "pool off", means no reserve either: what would be
   // created here would be trimmed at the next tick, for ever)
-  size_t reserve_b = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load()));
+  size_t reserve_b = reserve_target_bytes();
+  limbo_peak_[(limbo_tick_.fetch_add(1) + 1) % kLimboTicks].store(limbo_bytes_.load()); // (the slot of the tick that starts now)
   ExtentPool *primary = primary_pool_.load();
   // An engine that has not mapped or unmapped anything for KVCACHED_RESERVE_IDLE_S (default 10 s) gives its reserve back as well:
   // idle memory is what a co-located engine could use (the reference releases every page on unmap, csrc/page.cpp:17). The
@@ -713,7 +714,18 @@ void GpuContext::request_async_flush(int64_t within_us) {
 void GpuContext::park(uint64_t epoch, size_t bytes, std::function<void()> finish) {
   std::lock_guard<std::mutex> g(limbo_mu_);
   limbo_.push_back(Parked{epoch, bytes, std::move(finish)});
-  limbo_bytes_ += bytes;
+  const size_t now = (limbo_bytes_ += bytes);
+  auto &peak = limbo_peak_[limbo_tick_.load() % kLimboTicks];
+  if (now > peak.load()) peak.store(now);
+}
+
+size_t GpuContext::reserve_target_bytes() const {
+  const size_t cap = (size_t)std::max<int64_t>(0, options().pool_bytes.load());
+  const size_t base = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), cap);
+  if (!base) return 0;
+  size_t parked = 0;
+  for (auto &p : limbo_peak_) parked = std::max(parked, p.load());
+  return std::min(base + parked, cap);
 }
 
 void GpuContext::drain_limbo() {

@@ -1529,7 +1529,7 @@ void KvAllocator::map_slots(const std::vector<Slot> &slots, const std::vector<ph
 void KvAllocator::cold_start_reserve(ExtentPool *pool) {
   if (reserve_built_) return;
   const size_t unit = pool->page_bytes();
-  const size_t want = std::min((size_t)std::max<int64_t>(0, options().phys_reserve_bytes.load()), (size_t)std::max<int64_t>(0, options().pool_bytes.load())) / unit;
+  const size_t want = ctx_->reserve_target_bytes() / unit;
   if (!want || pool->idle_bytes() / unit >= want) {
     reserve_built_ = true;
     return;

@@ -177,6 +177,10 @@ public:
   void drain_limbo();                       // runs the finishers whose invalidation is over
   void flush_limbo();                       // invalidates if anything is parked, then drains
   size_t limbo_bytes() const { return limbo_bytes_.load(); }
+  // The idle memory the primary pool is kept at: KVCACHED_PHYS_RESERVE_MB (never above the pool's cap) plus - where unmaps park
+  // their pages - the most that was parked at once during the last second: parked pages are in transit, and a reserve of exactly
+  // one batch next to a parked batch leaves the next map call on the edge of having to invalidate for them itself.
+  size_t reserve_target_bytes() const;
   // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
   struct Foreground {
     GpuContext *c;
@@ -221,6 +225,9 @@ private:
   std::mutex limbo_mu_;
   std::deque<Parked> limbo_;
   std::atomic<size_t> limbo_bytes_{0};
+  static constexpr int kLimboTicks = 10;
+  std::atomic<size_t> limbo_peak_[kLimboTicks] = {}; // per housekeeping tick (one slot for ever where no thread ticks)
+  std::atomic<unsigned> limbo_tick_{0};
   std::atomic<int> housekeepers_{0};
   std::mutex mu_;
   std::unordered_map<size_t, std::unique_ptr<ExtentPool>> extent_pools_[2]; // [exportable], key: page bytes
