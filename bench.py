@@ -300,6 +300,14 @@ def compaction_roofline(capi, device):
                "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
                "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],
                "avg_launch_us": round(st["compact_ms"] / st["compact_launches"] * 1e3, 2)}
+        # the same buffers, moves as KVCacheManager.plan_compaction makes them on pages that are 30 % full at random:
+        # donors' live blocks ascending into receivers' free blocks ascending, instead of a random pairing
+        sys.path.insert(0, os.path.join(REPO, "benchmarks"))
+        from bench_compact import planned_moves
+        psrc, pdst = planned_moves(n_blocks, PAGE // block)
+        stp = timed([b.data_ptr() for b in bufs], psrc, pdst, block)
+        out["planner_moves_GBps"] = round(stp["compact_bytes"] / (stp["compact_ms"] * 1e-3) / 1e9, 1)
+        out["planner_moves"] = f"{len(psrc)} moves per region as KVCacheManager.plan_compaction orders them on 30 %-occupied pages (seed 2)"
         del bufs
         big = torch.randint(0, 127, (4 * GiB,), dtype=torch.int8, device=device)
         torch.cuda.synchronize()

@@ -18,8 +18,46 @@ VARIANTS = ["default (= lds+xcd+nt, 32 KiB tiles)", "reg+xcd+nt", "lds", "reg", 
 GEOMETRIES = ((2048 * KiB, 1, 2048, 1024),    # the ceiling: ONE region, 2 MiB blocks i -> i + 1024, i.e. a contiguous 2 GiB -> 2 GiB copy through the same kernel
               (32 * KiB, 64, 4096, 2048),     # Llama-3-8B: 32 layers x K/V regions, 32 KiB blocks
               (32 * KiB, 64, 4096, 256),
+              (32 * KiB, 64, 16384, 0),       # the same geometry, moves as KVCacheManager.plan_compaction makes them on 30 %-occupied pages (256 pages per region)
               (16 * KiB, 32, 8192, 2048),     # cfg 1 of the reference's tests: 16 layers, 16 KiB blocks
               (18432, 54, 4096, 1024))        # MLA-like: 16 tokens x 1152 B, 27 layers x 2
+
+
+def planned_moves(n_blocks, per_page, occupancy=0.3, seed=2):
+    """What KVCacheManager.plan_compaction produces on pages that are `occupancy` full at random ('random
+    30 %-occupied pages, seed 2'): the live blocks of the sparsest pages, ascending, go into the free blocks of the fullest
+    pages, ascending - whole donor pages only, as long as the receivers can absorb them."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    live = rng.random(n_blocks) < occupancy
+    pages = [(p, [b for b in range(p * per_page, (p + 1) * per_page) if live[b]], [b for b in range(p * per_page, (p + 1) * per_page) if not live[b]])
+             for p in range(n_blocks // per_page)]
+    donors = sorted(pages, key=lambda t: (len(t[1]), t[0]))
+    receivers = sorted(pages, key=lambda t: (-len(t[1]), t[0]))
+    moves, gone, taken, ri = [], set(), {}, 0
+    for pid, used, _ in donors:
+        if pid in taken:
+            break                                      # the donors have met the receivers
+        plan, need = [], len(used)
+        for rpid, _, rfree in receivers:
+            if need == 0:
+                break
+            if rpid == pid or rpid in gone:
+                continue
+            room = len(rfree) - taken.get(rpid, 0)
+            k = min(room, need)
+            if k > 0:
+                plan.append((rpid, rfree, k))
+                need -= k
+        if need:
+            break
+        it = iter(used)
+        for rpid, rfree, k in plan:
+            base = taken.get(rpid, 0)
+            moves += [(next(it), d) for d in rfree[base:base + k]]
+            taken[rpid] = base + k
+        gone.add(pid)
+    return [s for s, _ in moves], [d for _, d in moves]
 
 
 def setup(block, regions, n_blocks, moves):
@@ -30,6 +68,8 @@ def setup(block, regions, n_blocks, moves):
     src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
     if regions == 1:                             # the contiguous case
         src, dst = list(range(moves)), list(range(moves, 2 * moves))
+    if moves == 0:                               # the planner's moves on 30 %-occupied pages
+        src, dst = planned_moves(n_blocks, (2 << 20) // block)
     torch.cuda.synchronize()
     return bufs, [b.data_ptr() for b in bufs], src, dst
 
@@ -69,7 +109,7 @@ def main():
                 wall = time.perf_counter() - t0
                 st = capi.get_stats()
                 capi.set_option(capi.OPT_PROFILE, 0)
-                print(json.dumps(dict(block=block, regions=regions, moves=moves, variant=VARIANTS[variant],
+                print(json.dumps(dict(block=block, regions=regions, moves=len(src), planned=moves == 0, variant=VARIANTS[variant],
                                       launches=st["compact_launches"], event_GBps=round(st["compact_bytes"] / st["compact_ms"] / 1e6),
                                       wall_GBps=round(st["compact_bytes"] / wall / 1e9))), flush=True)
             capi.set_option(capi.OPT_COMPACT_VARIANT, 0)

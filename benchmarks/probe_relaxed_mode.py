@@ -42,6 +42,7 @@ def main():
             print(json.dumps({"rep": rep, "mode": name, "GBps": round(s["GBps"]), "map_zero_GBps": round(s["map_zero_GBps"]),
                               "p50_map_ms": round(s["p50_map_batch_ms"], 3), "unmap_us_per_page": round(s["unmap_us_per_page"], 3),
                               "driver_us_per_page": s.get("driver_us_per_page"), "handles_created": s.get("handles_created"),
+                              "host_us_per_call": s.get("host_us_per_call"), "tlb_shootdown_us": s.get("tlb_shootdown_us"),
                               "map_ms": [round(t * 1e3, 2) for t in r["per_step"]],
                               "unmap_ms": [round(t * 1e3, 2) for t in r["per_unmap"]]}), flush=True)
 

@@ -14,7 +14,7 @@ static constexpr size_t kFillSlabBytes = 64 * 1024;
 // Pointers (pages / regions) and moves one launch carries in its kernarg segment.
 static constexpr int kMaxPtrsPerLaunch = 1024; // 8 KiB of kernarg: a whole 1024-page batch is ONE launch (no drain/ramp between 4)
 static constexpr int kMaxRegionsPerLaunch = 128;
-static constexpr int kMaxMovesPerLaunch = 448; // 448 x 16 B + 128 x 8 B = 8 KiB of kernarg
+static constexpr int kMaxMovesPerLaunch = 448; // 448 x 16 B + 128 x 8 B = 8 KiB of kernarg (32 KiB / 1984 moves per launch was tried in round 3: fewer launches, but no faster on 32 KiB blocks and 8-10 % slower on 16-18 KiB blocks - every workgroup reads its three entries through the scalar cache)
 static constexpr int kMaxIdsPerLaunch = 1024; // block ids one index-kernel launch carries in its kernarg (8 KiB)
 
 // Zero `n` pages of `page_bytes` each (n <= kMaxPtrsPerLaunch). Asynchronous on `stream`.
