@@ -275,6 +275,45 @@ def test_the_unmap_side_invalidation_may_trail_the_call_but_pages_wait_for_it(la
     assert st["handles_created"] == st["handles_released"]
 
 
+def test_the_reserve_covers_what_is_parked(lanes, monkeypatch):
+    """Relaxed compat with a reserve of exactly ONE batch: the reserve target grows by what unmaps have parked
+    (GpuContext::reserve_target_bytes), so that the map batch behind an unmap finds idle pages next to the parked ones instead of
+    having their invalidation performed inside its own acquire - one invalidation per cycle once the reserve stands, and no memory
+    created from then on."""
+    from kvcached_amd import capi, vmm_ops as ops
+    monkeypatch.setenv("KVCACHED_UNMAP_INVALIDATION_US", "100000")          # (long: only map batches invalidate during the cycles)
+    monkeypatch.setenv("KVCACHED_ZERO_BACKFILL", "true")
+    monkeypatch.setenv("KVCACHED_PHYS_RESERVE_MB", "32")                    # = one batch of 16 pages
+    ops.init_kvcached(DEV, PAGE, False)
+    ts = ops.create_kv_tensors(64 * PAGE, 2, DEV, 1, 1, 0, True)
+    views = [ts[0].view(64, EPP)]
+    a, b = list(range(0, 16)), list(range(30, 46))
+    capi.reset_stats()
+    assert ops.map_to_kv_tensors([p * PAGE for p in a])
+    for rnd in range(6):                                                     # the reserve is brought along by these calls
+        cur, nxt = (a, b) if rnd % 2 == 0 else (b, a)
+        assert ops.unmap_from_kv_tensors([p * PAGE for p in cur])
+        assert ops.map_to_kv_tensors([p * PAGE for p in nxt])
+    s0 = capi.get_stats()
+    for rnd in range(6):
+        cur, nxt = (a, b) if rnd % 2 == 0 else (b, a)
+        assert ops.unmap_from_kv_tensors([p * PAGE for p in cur])
+        assert ops.map_to_kv_tensors([p * PAGE for p in nxt])
+        assert int(torch.count_nonzero(views[0][nxt[0]:nxt[-1] + 1])) == 0, rnd
+        _stamp(views, nxt, 3000 + 100 * rnd)
+        _check(views, nxt, 3000 + 100 * rnd)
+    s1 = capi.get_stats()
+    assert s1["tlb_shootdowns"] - s0["tlb_shootdowns"] <= 6 + 2, (s0, s1)   # the map batch's own (+ the library's thread, should this
+    #                                                                          process stall for 150 us between an unmap and its map); 12 = every acquire had to invalidate
+    assert s1["handles_created"] == s0["handles_created"], (s0, s1)
+    assert s1["handles_created"] >= 48, s1                                   # a mapped batch + a parked one + an idle one
+    assert ops.unmap_from_kv_tensors([p * PAGE for p in a])
+    capi.flush_unmaps()
+    ops.shutdown_kvcached()
+    st = capi.get_stats()
+    assert st["handles_created"] == st["handles_released"]
+
+
 def test_whole_tensors_can_be_read_next_to_background_mapping(lanes, monkeypatch):
     """"Unbacked VA reads as zeros, never faults" holds for slots at rest; a slot in transition - inside the one ioctl that backs
     it or gives it up - has invalid entries for ~2 us, and an access that lands there is a GPU fault
