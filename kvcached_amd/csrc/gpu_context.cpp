@@ -725,7 +725,9 @@ size_t GpuContext::reserve_target_bytes() const {
   if (!base) return 0;
   size_t parked = 0;
   for (auto &p : limbo_peak_) parked = std::max(parked, p.load());
-  return std::min(base + parked, cap);
+  // (at most the base again: the allowance is for the NEXT map batch, and a free() of many GiB must not make the housekeeping
+  // thread create as much on top of what a following alloc() takes back)
+  return std::min(base + std::min(parked, base), cap);
 }
 
 void GpuContext::drain_limbo() {

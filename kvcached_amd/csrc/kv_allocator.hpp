@@ -178,8 +178,9 @@ public:
   void flush_limbo();                       // invalidates if anything is parked, then drains
   size_t limbo_bytes() const { return limbo_bytes_.load(); }
   // The idle memory the primary pool is kept at: KVCACHED_PHYS_RESERVE_MB (never above the pool's cap) plus - where unmaps park
-  // their pages - the most that was parked at once during the last second: parked pages are in transit, and a reserve of exactly
-  // one batch next to a parked batch leaves the next map call on the edge of having to invalidate for them itself.
+  // their pages - the most that was parked at once during the last second (at most the base again): parked pages are in transit,
+  // and a reserve of exactly one batch next to a parked batch leaves the next map call on the edge of having to invalidate for
+  // them itself.
   size_t reserve_target_bytes() const;
   // a map / unmap call of an allocator is in progress (or was a moment ago): the background invalidation waits its turn
   struct Foreground {

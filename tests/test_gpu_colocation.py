@@ -20,8 +20,9 @@ BLOCKS_PER_GIB = GiB // (PAGE * LAYERS * 2) * 64
 RESERVE_MB = 1024                                        # KVCACHED_PHYS_RESERVE_MB: idle pages the pool never gives back (and pre-creates)
 
 
-def _engine(name, conn):
+def _engine(name, conn, unmap_invalidation_us=0):
     os.environ["KVCACHED_IPC_NAME"] = name
+    os.environ["KVCACHED_UNMAP_INVALIDATION_US"] = str(unmap_invalidation_us)   # 0: strict compat (the default); > 0: relaxed
     os.environ["KVCACHED_PAGE_PREALLOC_ENABLED"] = "true"          # the watcher thread (10 Hz housekeeping) runs with it
     os.environ["KVCACHED_LOG_LEVEL"] = "ERROR"
     os.environ["KVCACHED_POOL_IDLE_MS"] = "500"
@@ -79,13 +80,14 @@ def _wait_for(fn, pred, timeout):
         time.sleep(0.05)
 
 
-def test_two_engines_share_one_gpu():
+@pytest.mark.parametrize("unmap_invalidation_us", [0, 300])
+def test_two_engines_share_one_gpu(unmap_invalidation_us):
     ctx = mp.get_context("spawn")
     pipes, procs = [], []
     ballast = None
     for name in ("kvc_colo_a", "kvc_colo_b"):
         parent, child = ctx.Pipe()
-        p = ctx.Process(target=_engine, args=(f"{name}_{os.getpid()}", child), daemon=True)
+        p = ctx.Process(target=_engine, args=(f"{name}_{os.getpid()}", child, unmap_invalidation_us), daemon=True)
         p.start()
         pipes.append(parent)
         procs.append(p)
