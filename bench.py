@@ -646,9 +646,9 @@ def shared_pool_in_children(rank, world):
     env["KVCACHED_IPC_NAME"] = f"kvc_bench_share_{port}"      # the same on every rank: the fd sockets live under one directory
     env.pop("KVC_BENCH_TEST_FAIL_RANK", None)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shared-pool-leg"], env=env, capture_output=True, text=True, timeout=240)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shared-pool-leg"], env=env, capture_output=True, text=True, timeout=150)
     except subprocess.TimeoutExpired:
-        return {"error": "the shared-pool leg did not finish within 240 s"}
+        return {"error": "the shared-pool leg did not finish within 150 s"}
     if rank != 0:
         return None
     js = [l for l in r.stdout.splitlines() if l.startswith("{")]
