@@ -37,7 +37,7 @@ def planned_moves(n_blocks, per_page, occupancy=0.3, seed=2):
     moves, gone, taken, ri = [], set(), {}, 0
     for pid, used, _ in donors:
         if pid in taken:
-            break                                      # the donors have met the receivers
+            continue                                   # (already promised blocks as a receiver)
         plan, need = [], len(used)
         for rpid, _, rfree in receivers:
             if need == 0:

@@ -285,6 +285,29 @@ def test_compaction_planner(cpu_ops):
     del m
 
 
+def test_the_compaction_benchmarks_moves_are_the_planners(cpu_ops):
+    """bench.py / benchmarks/bench_compact.py time compact_blocks on `planned_moves` (pages 30 % full at random)
+    without a manager in the loop: the list must be what KVCacheManager.plan_compaction makes of that occupancy."""
+    import sys
+    import numpy as np
+    ops, capi = cpu_ops
+    import kvcached_amd.kv_cache_manager as kcm
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks"))
+    from bench_compact import planned_moves
+    n_blocks, per_page = 64 * 64, 64
+    ops.create_kv_tensors(64 * PAGE * 2, 1, "cpu", 2, 2, 0, False)
+    m = kcm.KVCacheManager(num_blocks=n_blocks, block_size=16, cell_size=2048, num_layers=2)
+    assert m._post_init_done.wait(10)
+    a = m.alloc(n_blocks)
+    assert sorted(a) == list(range(n_blocks))
+    live = np.random.default_rng(2).random(n_blocks) < 0.3
+    m.free([b for b in a if not live[b]])
+    moves = m.plan_compaction()
+    src, dst = planned_moves(n_blocks, per_page)
+    assert len(moves) > 500 and moves == list(zip(src, dst))
+    del m
+
+
 def test_async_unmap_queue_on_the_cpu_device(cpu_ops):
     """KVC_OPT_ASYNC_UNMAP's queue/reclaimer/re-backing logic without a GPU (the cpu device has no driver calls, the
     state machine and the threads are the same): several threads map and unmap disjoint slot ranges while the
