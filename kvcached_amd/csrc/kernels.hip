@@ -115,6 +115,7 @@ struct CompactArgs {
 static_assert(sizeof(CompactArgs) <= 8192, "kernarg segment budget");
 
 static constexpr int kCompactThreads = 256;          // 4 waves
+static constexpr int kCompactWaves = kCompactThreads / 64;
 static constexpr int kCompactTile = 16 * 1024;       // bytes per workgroup: 4 waves x 4 x 1 KiB
 static constexpr int kPiece = 1024;                  // one wave-instruction
 static constexpr int kPiecesPerWave = kCompactTile / kPiece / (kCompactThreads / 64);
@@ -230,12 +231,16 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(Com
 }
 
 // Variants 6 (LDS-staged) and 7 (register-staged) with 32 KiB tiles: every wave has 8 KiB in flight instead of 4.
-template <bool LDS>
+// BLOCKED (variant 9): an XCD takes a contiguous eighth of the (region, move) pairs instead of every eighth pair - neighbouring
+// moves of a planner-made list share their source and destination pages, and an XCD has its own L2 / translation cache.
+template <bool LDS, bool BLOCKED = false>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_big_kernel(CompactArgs a, unsigned n_moves, unsigned n_regions,
                                                                               unsigned tiles_per_block, unsigned block_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[LDS ? kCompactTileBig : 16];
   const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-  const unsigned q = i / tiles_per_block, t = i - q * tiles_per_block, pair = q * 8u + x;
+  const unsigned q = i / tiles_per_block, t = i - q * tiles_per_block;
+  const unsigned pair = BLOCKED ? x * ((n_moves * n_regions + 7u) >> 3) + q : q * 8u + x;
+  if (BLOCKED && q >= ((n_moves * n_regions + 7u) >> 3)) return;
   if (pair >= n_moves * n_regions) return;
   const unsigned r = pair / n_moves, m = pair - r * n_moves;
   const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTileBig;
@@ -247,22 +252,22 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_big_kernel(Com
   if (LDS) {
 #pragma unroll
     for (int k = 0; k < kPiecesPerWaveBig; ++k) {
-      const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+      const unsigned off = (k * kCompactWaves + wave) * kPiece + lane * 16;
       if (full || off < limit)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                         (__attribute__((address_space(3))) void *)(tile + (wave * kPiecesPerWaveBig + k) * kPiece), 16, 0, 2);
+                                         (__attribute__((address_space(3))) void *)(tile + (k * kCompactWaves + wave) * kPiece), 16, 0, 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (full) {
       v4u v[kPiecesPerWaveBig];
 #pragma unroll
-      for (int k = 0; k < kPiecesPerWaveBig; ++k) v[k] = *reinterpret_cast<const v4u *>(tile + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16);
+      for (int k = 0; k < kPiecesPerWaveBig; ++k) v[k] = *reinterpret_cast<const v4u *>(tile + (k * kCompactWaves + wave) * kPiece + lane * 16);
 #pragma unroll
       for (int k = 0; k < kPiecesPerWaveBig; ++k)
-        __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+        __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (k * kCompactWaves + wave) * kPiece + lane * 16));
     } else {
       for (int k = 0; k < kPiecesPerWaveBig; ++k) {
-        const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+        const unsigned off = (k * kCompactWaves + wave) * kPiece + lane * 16;
         if (off < limit) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(tile + off);
       }
     }
@@ -270,13 +275,13 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_big_kernel(Com
     v4u v[kPiecesPerWaveBig];
 #pragma unroll
     for (int k = 0; k < kPiecesPerWaveBig; ++k)
-      v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+      v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src + (k * kCompactWaves + wave) * kPiece + lane * 16));
 #pragma unroll
     for (int k = 0; k < kPiecesPerWaveBig; ++k)
-      __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16));
+      __builtin_nontemporal_store(v[k], reinterpret_cast<v4u *>(dst + (k * kCompactWaves + wave) * kPiece + lane * 16));
   } else {
     for (int k = 0; k < kPiecesPerWaveBig; ++k) {
-      const unsigned off = (wave * kPiecesPerWaveBig + k) * kPiece + lane * 16;
+      const unsigned off = (k * kCompactWaves + wave) * kPiece + lane * 16;
       if (off < limit) *reinterpret_cast<v4u *>(dst + off) = *reinterpret_cast<const v4u *>(src + off);
     }
   }
@@ -310,14 +315,22 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
   // Default since round 3: LDS-staged, XCD-aware, non-temporal, 32 KiB tiles (8 KiB in flight per wave): the same rate as the
   // 16 KiB tiles on 32 KiB blocks (5.47 vs 5.50 TB/s), +2.6 % on 16 KiB blocks and +12 % on ragged 18 KiB MLA blocks (one tile per
   // block instead of a full one and a 2 KiB tail) - profiles/r03_compact_bench.jsonl. Variant 8 is the 16 KiB-tile form.
-  if (variant == 0) variant = 6;
-  if (variant == 6 || variant == 7) {
+  // Since the end of round 3 the default hands every XCD a contiguous eighth of the (region, move) pairs (variant 9) instead of
+  // every eighth pair (variant 6): with 64 regions an XCD then works inside 8 of them, and its L2 / translation cache sees an
+  // eighth of the pages - +10..18 % on the Llama-3-8B geometry, random or planner-ordered moves alike
+  // (profiles/r03_compact_bench_blocked.jsonl).
+  if (variant == 0) variant = 9;
+  if (variant == 6 || variant == 7 || variant == 9 || variant == 10) {
     const unsigned tiles_big = (unsigned)((block_bytes + kCompactTileBig - 1) / kCompactTileBig);
     const size_t g = (size_t)tiles_big * ((pairs + 7) / 8 * 8);
     if (variant == 6)
       compact_blocks_big_kernel<true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
-    else
+    else if (variant == 7)
       compact_blocks_big_kernel<false><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
+    else if (variant == 9)
+      compact_blocks_big_kernel<true, true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
+    else
+      compact_blocks_big_kernel<false, true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
     return hipGetLastError();
   }
   switch (variant) {

@@ -23,9 +23,9 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
 
 // Copy blocks inside each region: for r < n_regions, m < n_moves:
 //   bases[r] + dst[m]*block_bytes  <-  bases[r] + src[m]*block_bytes
-// n_regions <= kMaxRegionsPerLaunch, n_moves <= kMaxMovesPerLaunch. variant 0 (= 6) = LDS-staged
-// (LDS-DMA in, ds_read_b128 + global_store out), XCD-aware block placement, non-temporal accesses, 32 KiB tiles; 7 = the same
-// register-staged; 8 and 1 = LDS / register-staged with 16 KiB tiles (8: the default until round 3); 2/3 = LDS/register-staged
+// n_regions <= kMaxRegionsPerLaunch, n_moves <= kMaxMovesPerLaunch. variant 0 (= 9) = LDS-staged
+// (LDS-DMA in, ds_read_b128 + global_store out), a contiguous eighth of the (region, move) pairs per XCD, non-temporal accesses,
+// 32 KiB tiles; 10 = the same register-staged; 6 / 7 = LDS / register-staged with every eighth pair per XCD (the default of most of round 3); 8 and 1 = LDS / register-staged with 16 KiB tiles (8: the default until round 3); 2/3 = LDS/register-staged
 // with the plain interleaved placement and temporal accesses; 4/5 = LDS/register-staged XCD-aware with temporal accesses (A/B runs).
 hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_t *src, const int64_t *dst, int n_moves,
                                  size_t block_bytes, hipStream_t stream, int variant = 0);

@@ -69,7 +69,7 @@ if ckt:
                        "algorithmic_read_bytes": algo, "algorithmic_write_bytes": algo, "pmc_write_bytes": w, "pmc_read_bytes": f,
                        "traffic_over_algorithmic": round((w + f) / (2 * algo), 4),
                        "GBps_read_plus_write": round(2 * algo / (sum(d) / len(d)) / 1e3, 1)})
-    json.dump({"kernel": "kvc::compact_blocks_big_kernel<true> (LDS-staged, XCD-aware, non-temporal, 32 KiB tiles)", "geometry": "Llama-3-8B: 64 regions x 32 KiB blocks",
+    json.dump({"kernel": "kvc::compact_blocks_big_kernel<true, true> (LDS-staged, a contiguous eighth of the pairs per XCD, non-temporal, 32 KiB tiles)", "geometry": "Llama-3-8B: 64 regions x 32 KiB blocks",
                "note": "rocprofv3 --kernel-trace for durations; WRITE_SIZE and FETCH_SIZE in separate --pmc passes; FETCH_SIZE doubled (gfx950 tallies 128 B requests as 64 B)",
                "per_launch": shapes}, open(f"profiles/{R}_compact_traffic.json", "w"), indent=1)
     shutil.copy(newest("gpurun_out/prof_compact_kt/runc/*_kernel_stats.csv"), f"profiles/{R}_rocprofv3_compact_kernel_stats.csv")

@@ -37,8 +37,9 @@ next to it in the line:
 (`profiles/r03_rocprofv3_kernel_stats.csv` has them together with three 512 MiB fills of the cold start; per shape: `profiles/zero_fill_traffic.json`) = {2147483648 / avg_ns / 1000:.2f} TB/s = {2147483648 / avg_ns / 8000:.3f} of the HBM peak**; the bench line of the same session has {d['roofline']['avg_launch_us']:.1f} µs =
 {d['roofline']['achieved'] / 1000:.2f} TB/s (frac {d['roofline']['frac']:.3f}) from the in-library HIP events on the scrub stream. PMC (own passes, same command): WRITE_SIZE =
 2 097 152 KiB per launch = the algorithmic bytes exactly, FETCH_SIZE 0.23 MB (`profiles/zero_fill_traffic.json`).
-`compact_blocks`: {rc['achieved'] / 1000:.2f} TB/s = {rc['frac']:.3f} of peak, {rc['frac_of_copy_ceiling']:.3f} of the same-session copy ceiling of {rc['copy_ceiling_GBps'] / 1000:.2f} (§5;
-in `rocprofv3`: 354.8 µs per 448-move launch = 5.30 TB/s, traffic 1.0004 × algorithmic, `profiles/r03_compact_traffic.json`).
+`compact_blocks` (every XCD inside its own eighth of the regions, §5): {rc['achieved'] / 1000:.2f} TB/s = **{rc['frac']:.3f} of peak** on random moves, {rc.get('planner_moves_GBps', 0) / 1000:.2f} on planner-ordered ones; the
+contiguous 2 GiB → 2 GiB copy of the same session through the same kernel: {rc['copy_ceiling_GBps'] / 1000:.2f}; torch's D2D copy: {rc['torch_d2d_copy_GBps'] / 1000:.2f}
+(`rocprofv3` + PMC of this kernel: `profiles/r03_compact_traffic.json`).
 Configs 2–4 in full and the soaks of the final library: `profiles/r03_bench_vmm.jsonl`, `r03_bench_elastic.jsonl`,
 `r03_bench_tp_ipc.jsonl`, `r03_soak.jsonl`, `r03_soak_long.jsonl` (§4.11, §7).
 
