@@ -290,25 +290,46 @@ def compaction_roofline(capi, device):
     block, regions, n_blocks, moves = 32 * 1024, 64, 4096, 2048
     capi.init(device, PAGE, False)
     try:
-        bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device=device) for _ in range(regions)]
+        # The data where it lives in the product: 64 regions (32 layers x K/V) reserved and backed BY THE LIBRARY - 64 page ids,
+        # every 2 MiB slot its own page-table entry (8 GiB) - with random contents (what is moved is bytes, not zeros).
         ids = np.random.default_rng(0).permutation(n_blocks)[:2 * moves]
         src, dst = [int(x) for x in ids[:moves]], [int(x) for x in ids[moves:]]
+        regs = capi.create_kv_tensors(2 * (n_blocks * block), 1, device, regions // 2, 2, 0, False)
+        page_ids = n_blocks * block // PAGE
+        capi.map_to_kv_tensors([p * PAGE for p in range(page_ids)])
+        bases = capi.get_region_bases(0)
+        assert len(bases) == regions, (len(bases), regions)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")                         # (the runtime torch has loaded already)
+        noise = torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device=device)
         torch.cuda.synchronize()
-        st = timed([b.data_ptr() for b in bufs], src, dst, block)
+        for b in bases:                                             # device-to-device (kind 3) into the mapped range
+            rc = hip.hipMemcpy(ctypes.c_void_p(b), ctypes.c_void_p(noise.data_ptr()), ctypes.c_size_t(n_blocks * block), 3)
+            assert rc == 0, f"hipMemcpy into a KV region failed: {rc}"
+        del noise
+        torch.cuda.synchronize()
+        st = timed(bases, src, dst, block)
         achieved = st["compact_bytes"] / (st["compact_ms"] * 1e-3) / 1e9
         out = {"kernel": "compact_blocks (LDS-staged, a contiguous eighth of the pairs per XCD, non-temporal, 32 KiB tiles)", "bound": "hbm", "achieved": round(achieved, 1),
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                "bytes": "read + written = 2 x block_bytes x regions per moved block (4 MiB per Llama-3-8B block)",
+               "where": f"{regions} KV regions reserved and backed by the library ({page_ids} page ids = {regions * page_ids} slots of 2 MiB), random pairing of {moves} moves",
                "launches": st["compact_launches"], "bytes_per_launch": st["compact_bytes"] // st["compact_launches"],
                "avg_launch_us": round(st["compact_ms"] / st["compact_launches"] * 1e3, 2)}
-        # the same buffers, moves as KVCacheManager.plan_compaction makes them on pages that are 30 % full at random:
+        # the same regions, moves as KVCacheManager.plan_compaction makes them on pages that are 30 % full at random:
         # donors' live blocks ascending into receivers' free blocks ascending, instead of a random pairing
         sys.path.insert(0, os.path.join(REPO, "benchmarks"))
         from bench_compact import planned_moves
         psrc, pdst = planned_moves(n_blocks, PAGE // block)
-        stp = timed([b.data_ptr() for b in bufs], psrc, pdst, block)
+        stp = timed(bases, psrc, pdst, block)
         out["planner_moves_GBps"] = round(stp["compact_bytes"] / (stp["compact_ms"] * 1e-3) / 1e9, 1)
         out["planner_moves"] = f"{len(psrc)} moves per region as KVCacheManager.plan_compaction orders them on 30 %-occupied pages (seed 2)"
+        capi.unmap_from_kv_tensors([p * PAGE for p in range(page_ids)])
+        # the same moves on 64 torch buffers (what rounds 1-3 measured; physically contiguous 128 MiB each)
+        bufs = [torch.randint(0, 127, (n_blocks * block,), dtype=torch.int8, device=device) for _ in range(regions)]
+        torch.cuda.synchronize()
+        stt = timed([b.data_ptr() for b in bufs], src, dst, block)
+        out["on_torch_buffers_GBps"] = round(stt["compact_bytes"] / (stt["compact_ms"] * 1e-3) / 1e9, 1)
         del bufs
         big = torch.randint(0, 127, (4 * GiB,), dtype=torch.int8, device=device)
         torch.cuda.synchronize()

@@ -77,6 +77,9 @@ def setup(block, regions, n_blocks, moves):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--profile-shape", action="store_true", help="Llama-3-8B geometry, default variant, 6 calls, no sweep")
+    ap.add_argument("--kv-regions", action="store_true",
+                    help="the Llama-3-8B geometry on REAL KV regions: 64 page ids mapped through the library (64 regions of 2 MiB slots, "
+                         "each slot its own page-table entry) instead of torch buffers")
     args = ap.parse_args()
     os.environ.setdefault("KVCACHED_LOG_LEVEL", "ERROR")
     import torch
@@ -85,6 +88,33 @@ def main():
     from kvcached_amd import capi
     capi.init("cuda:0", 2 << 20, False)
     try:
+        if args.kv_regions:
+            import numpy as np
+            page, block, n_blocks = 2 << 20, 32 * KiB, 4096
+            capi.create_kv_tensors(2 * 64 * page, 1, "cuda:0", 32, 2, 0, False)       # 32 layers x K/V, 64 page ids each
+            capi.map_to_kv_tensors([p * page for p in range(64)])
+            torch.cuda.synchronize()
+            bases = capi.get_region_bases(0)
+            ids = np.random.default_rng(0).permutation(n_blocks)[:4096]
+            cases = {"random pairing, 2048 moves": ([int(x) for x in ids[:2048]], [int(x) for x in ids[2048:]]),
+                     "planner-ordered moves on 30 %-occupied pages": planned_moves(n_blocks, page // block)}
+            for label, (src, dst) in cases.items():
+                for variant, vname in ((0, VARIANTS[0]), (6, VARIANTS[6]), (10, VARIANTS[10])):
+                    capi.set_option(capi.OPT_COMPACT_VARIANT, variant)
+                    for _ in range(2):
+                        capi.compact_blocks(bases, src, dst, block)
+                    capi.set_option(capi.OPT_PROFILE, 1)
+                    capi.reset_stats()
+                    for _ in range(5):
+                        capi.compact_blocks(bases, src, dst, block, sync=False)
+                    capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
+                    st = capi.get_stats()
+                    capi.set_option(capi.OPT_PROFILE, 0)
+                    print(json.dumps(dict(where="KV regions mapped by the library (2 MiB slots)", regions=len(bases), block=block, moves=len(src), what=label,
+                                          variant=vname, event_GBps=round(st["compact_bytes"] / st["compact_ms"] / 1e6))), flush=True)
+            capi.set_option(capi.OPT_COMPACT_VARIANT, 0)
+            capi.unmap_from_kv_tensors([p * page for p in range(64)])
+            return
         if args.profile_shape:
             block, regions, n_blocks, moves = GEOMETRIES[1]
             bufs, bases, src, dst = setup(block, regions, n_blocks, moves)
