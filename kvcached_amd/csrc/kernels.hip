@@ -37,7 +37,9 @@ struct PageTable {
 // Measured on MI355X (tools/fill_bench.cpp, 2 GiB of 2 MiB pages, sequential and shuffled lists):
 // 6.2 TB/s with this mapping vs 5.5 TB/s interleaved; hipMemsetAsync reaches 6.4 TB/s on the same
 // (contiguous) range. The placement is a speed heuristic only: any block->XCD assignment is correct.
-template <int THREADS, bool NT, bool XCD_PAGES>
+// XCD_BLOCKED (variant 4, A/B): XCD x owns the pages [x * ceil(n/8), (x+1) * ceil(n/8)) - a contiguous eighth of the list (the
+// list arrives sorted into runs of up to 64 adjacent pages of one physical extent) - instead of every eighth page.
+template <int THREADS, bool NT, bool XCD_PAGES, bool XCD_BLOCKED = false>
 __global__ __launch_bounds__(THREADS) void zero_fill_pages_kernel(PageTable pages, unsigned slabs_per_page,
                                                                    unsigned n_pages) {
   constexpr int STORES = (int)(kFillSlabBytes / 16 / THREADS);
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(THREADS) void zero_fill_pages_kernel(PageTable page
     const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
     const unsigned q = i / slabs_per_page;
     slab = i - q * slabs_per_page;
-    page = q * 8u + x;
+    page = XCD_BLOCKED ? x * ((n_pages + 7u) >> 3) + q : q * 8u + x;
     if (page >= n_pages) return; // the grid is padded to a multiple of 8 pages (wave-uniform exit)
   } else {
     page = blockIdx.x / slabs_per_page;
@@ -84,6 +86,9 @@ hipError_t launch_zero_fill_pages(void *const *pages, int n, size_t page_bytes, 
     break;
   case 3:
     zero_fill_pages_kernel<1024, false, true><<<dim3((unsigned)grid_xcd), dim3(1024), 0, stream>>>(t, slabs, (unsigned)n);
+    break;
+  case 4: // a contiguous eighth of the page list per XCD
+    zero_fill_pages_kernel<512, false, true, true><<<dim3((unsigned)grid_xcd), dim3(512), 0, stream>>>(t, slabs, (unsigned)n);
     break;
   default:
     zero_fill_pages_kernel<512, false, true><<<dim3((unsigned)grid_xcd), dim3(512), 0, stream>>>(t, slabs, (unsigned)n);

@@ -40,7 +40,16 @@ def _oracle_fill(lib, host: np.ndarray, offsets, page_bytes):
     (6 * MiB, 6, 3, 4),             # page size that is not a power of two (3 x 2 MiB)
     (2 * MiB, 4, 0, 5),             # empty batch
 ])
-def test_zero_fill_matches_oracle(capi, oracle_lib, page_bytes, n_pages, n_sel, seed):
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])   # 0: XCD x owns pages x, x+8, ...; 4: a contiguous eighth of the list; 1-3: A/B forms
+def test_zero_fill_matches_oracle(capi, oracle_lib, page_bytes, n_pages, n_sel, seed, variant):
+    capi.set_option(capi.OPT_FILL_VARIANT, variant)
+    try:
+        _zero_fill_case(capi, oracle_lib, page_bytes, n_pages, n_sel, seed)
+    finally:
+        capi.set_option(capi.OPT_FILL_VARIANT, 0)
+
+
+def _zero_fill_case(capi, oracle_lib, page_bytes, n_pages, n_sel, seed):
     rng = np.random.default_rng(seed)
     total = page_bytes * n_pages
     dev = torch.empty(total, dtype=torch.uint8, device="cuda:0")
