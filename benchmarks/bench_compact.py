@@ -14,7 +14,7 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 KiB = 1 << 10
-VARIANTS = ["default (= lds+nt, 32 KiB tiles, an eighth of the pairs per XCD)", "reg+xcd+nt", "lds", "reg", "lds+xcd", "reg+xcd", "lds+xcd+nt, 32 KiB tiles", "reg+xcd+nt, 32 KiB tiles", "lds+xcd+nt, 16 KiB tiles (default until r03)", "lds+nt, 32 KiB tiles, an eighth of the pairs per XCD", "reg+nt, 32 KiB tiles, an eighth of the pairs per XCD"]
+VARIANTS = ["default (= lds+nt, 32 KiB tiles, an eighth of the pairs per XCD)", "reg+xcd+nt", "lds", "reg", "lds+xcd", "reg+xcd", "lds+xcd+nt, 32 KiB tiles", "reg+xcd+nt, 32 KiB tiles", "lds+xcd+nt, 16 KiB tiles (default until r03)", "lds+nt, 32 KiB tiles, an eighth of the pairs per XCD", "reg+nt, 32 KiB tiles, an eighth of the pairs per XCD", "lds+nt, 32 KiB tiles, an eighth of the pairs per XCD, XCDs out of step"]
 GEOMETRIES = ((2048 * KiB, 1, 2048, 1024),    # the ceiling: ONE region, 2 MiB blocks i -> i + 1024, i.e. a contiguous 2 GiB -> 2 GiB copy through the same kernel
               (32 * KiB, 64, 4096, 2048),     # Llama-3-8B: 32 layers x K/V regions, 32 KiB blocks
               (32 * KiB, 64, 4096, 256),
@@ -99,7 +99,7 @@ def main():
             cases = {"random pairing, 2048 moves": ([int(x) for x in ids[:2048]], [int(x) for x in ids[2048:]]),
                      "planner-ordered moves on 30 %-occupied pages": planned_moves(n_blocks, page // block)}
             for label, (src, dst) in cases.items():
-                for variant, vname in ((0, VARIANTS[0]), (6, VARIANTS[6]), (10, VARIANTS[10])):
+                for variant, vname in ((0, VARIANTS[0]), (6, VARIANTS[6]), (10, VARIANTS[10]), (11, VARIANTS[11]), (0, VARIANTS[0]), (11, VARIANTS[11])):
                     capi.set_option(capi.OPT_COMPACT_VARIANT, variant)
                     for _ in range(2):
                         capi.compact_blocks(bases, src, dst, block)

@@ -267,14 +267,19 @@ __global__ __launch_bounds__(kCompactThreads) void compact_blocks_reg_kernel(Com
 // Variants 6 (LDS-staged) and 7 (register-staged) with 32 KiB tiles: every wave has 8 KiB in flight instead of 4.
 // BLOCKED (variant 9): an XCD takes a contiguous eighth of the (region, move) pairs instead of every eighth pair - neighbouring
 // moves of a planner-made list share their source and destination pages, and an XCD has its own L2 / translation cache.
-template <bool LDS, bool BLOCKED = false>
+// ROTATED (variant 11): as BLOCKED, and XCD x starts x * (an eighth of its range + 57) pairs into its range (wrapping round):
+// with every XCD walking the SAME move list through its own regions in step, the eight streams would read the same block index of
+// regions that lie a power of two apart at the same moment.
+template <bool LDS, bool BLOCKED = false, bool ROTATED = false>
 __global__ __launch_bounds__(kCompactThreads) void compact_blocks_big_kernel(CompactArgs a, unsigned n_moves, unsigned n_regions,
                                                                               unsigned tiles_per_block, unsigned block_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[LDS ? kCompactTileBig : 16];
   const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-  const unsigned q = i / tiles_per_block, t = i - q * tiles_per_block;
-  const unsigned pair = BLOCKED ? x * ((n_moves * n_regions + 7u) >> 3) + q : q * 8u + x;
-  if (BLOCKED && q >= ((n_moves * n_regions + 7u) >> 3)) return;
+  const unsigned t = i % tiles_per_block;
+  unsigned q = i / tiles_per_block;
+  const unsigned per_xcd = (n_moves * n_regions + 7u) >> 3;
+  if (ROTATED) q = (q + x * ((per_xcd >> 3) + 57u)) % per_xcd;
+  const unsigned pair = BLOCKED ? x * per_xcd + q : q * 8u + x;
   if (pair >= n_moves * n_regions) return;
   const unsigned r = pair / n_moves, m = pair - r * n_moves;
   const char *src = static_cast<const char *>(a.base[r]) + a.src[m] * (int64_t)block_bytes + (size_t)t * kCompactTileBig;
@@ -354,7 +359,7 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
   // eighth of the pages - +10..18 % on the Llama-3-8B geometry, random or planner-ordered moves alike
   // (profiles/r03_compact_bench_blocked.jsonl).
   if (variant == 0) variant = 9;
-  if (variant == 6 || variant == 7 || variant == 9 || variant == 10) {
+  if (variant == 6 || variant == 7 || variant == 9 || variant == 10 || variant == 11) {
     const unsigned tiles_big = (unsigned)((block_bytes + kCompactTileBig - 1) / kCompactTileBig);
     const size_t g = (size_t)tiles_big * ((pairs + 7) / 8 * 8);
     if (variant == 6)
@@ -363,8 +368,10 @@ hipError_t launch_compact_blocks(void *const *bases, int n_regions, const int64_
       compact_blocks_big_kernel<false><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
     else if (variant == 9)
       compact_blocks_big_kernel<true, true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
-    else
+    else if (variant == 10)
       compact_blocks_big_kernel<false, true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
+    else
+      compact_blocks_big_kernel<true, true, true><<<dim3((unsigned)g), blk, 0, stream>>>(a, nm, nr, tiles_big, bb);
     return hipGetLastError();
   }
   switch (variant) {

@@ -104,7 +104,7 @@ def _oracle_compact(lib, hosts, src, dst, block_bytes):
     lib.okvc_compact_blocks(bases, len(hosts), T._arr(src), T._arr(dst), len(src), block_bytes)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10])   # 9: an eighth of the pairs per XCD; 0 = 6: the 32 KiB-tile default; 8: the 16 KiB-tile default of rounds 1-2
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11])   # 9: an eighth of the pairs per XCD; 0 = 6: the 32 KiB-tile default; 8: the 16 KiB-tile default of rounds 1-2
 @pytest.mark.parametrize("block_bytes,n_blocks,n_regions,n_moves,seed", [
     (32 * KiB, 256, 4, 40, 0),       # Llama-3-8B block (16 tok x 2048 B): two full 16 KiB tiles
     (16 * KiB, 128, 3, 7, 1),        # cfg-1 block: exactly one tile
