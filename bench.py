@@ -289,6 +289,8 @@ def compaction_roofline(capi, device):
 
     block, regions, n_blocks, moves = 32 * 1024, 64, 4096, 2048
     capi.init(device, PAGE, False)
+    if os.environ.get("KVC_BENCH_COMPACT_VARIANT"):                 # A/B runs of the kernel's placement variants; default: the library's
+        capi.set_option(capi.OPT_COMPACT_VARIANT, int(os.environ["KVC_BENCH_COMPACT_VARIANT"]))
     try:
         # The data where it lives in the product: 64 regions (32 layers x K/V) reserved and backed BY THE LIBRARY - 64 page ids,
         # every 2 MiB slot its own page-table entry (8 GiB) - with random contents (what is moved is bytes, not zeros).
