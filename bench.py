@@ -761,6 +761,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # stdout carries ONE line, the JSON: whatever the libraries below print there (gloo's "[Gloo] Rank 0 is connected to ..." of
+    # the fan-out's wake group, a runtime's banner) is sent to stderr from here on, at the level of the file descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # Rehearsal of the launcher / fan-out / JSON contract without a GPU (tests only, KVC_BENCH_REHEARSAL=cpu): the
     # library's "cpu" device keeps the books and maps nothing, so the line it prints is labelled as no measurement.
     rehearsal = os.environ.get("KVC_BENCH_REHEARSAL") == "cpu"
@@ -790,7 +795,7 @@ def main():
                ("GBps", "p50_map_batch_ms", "map_us_per_page", "handles_created", "driver_us_per_page")}
         out["create_split"] = r1.get("create_split")
         out["per_batch_ms"] = [round(x * 1e3, 1) for x in r1["per_step"]]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         return
 
     # N = 1: before this process maps anything (it has only asked torch for the device), a child - a fresh process - runs the
@@ -985,7 +990,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
                 line["reference_hip_path_on_this_box"] = reference_on_box(args.steps, args.warmup)
                 line["reference_hip_path_growth_burst"] = reference_on_box(24, 4, burst=True)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
