@@ -24,6 +24,7 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
+    assert out.stdout.strip().splitlines() == lines, out.stdout     # nothing else on stdout (gloo's connection notice goes to stderr)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"] == [0, 1]
     assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
