@@ -40,7 +40,7 @@ def _oracle_fill(lib, host: np.ndarray, offsets, page_bytes):
     (6 * MiB, 6, 3, 4),             # page size that is not a power of two (3 x 2 MiB)
     (2 * MiB, 4, 0, 5),             # empty batch
 ])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])   # 0: XCD x owns pages x, x+8, ... of the stride-permuted table; 5: of the caller's order; 4: a contiguous eighth; 1-3: A/B forms
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])   # 0: XCD x owns pages x, x+8, ... of the table in its fixed pseudo-random order; 5: of the caller's order; 4: a contiguous eighth; 1-3: A/B forms
 def test_zero_fill_matches_oracle(capi, oracle_lib, page_bytes, n_pages, n_sel, seed, variant):
     capi.set_option(capi.OPT_FILL_VARIANT, variant)
     try:
