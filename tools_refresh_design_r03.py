@@ -13,6 +13,14 @@ ft, ref, refb, rc = d["growth_burst_first_touch"], d["reference_hip_path_on_this
 kt = json.load(open("profiles/zero_fill_traffic.json"))["rocprofv3_kernel_trace"]["per_shape"]["1024_pages"]
 calls, avg_ns = kt["launches"], kt["avg_us"] * 1000
 relaxed = v["compat_unmap_invalidation_trails_300us"]
+_f, _s = [json.loads(l) for l in open("profiles/r03_bench_alloc.jsonl")]
+ba = (f"`available_size()` {_f['available_size_us']:.2f} µs [0.52 C++ / 6.52 Python there]; `group_indices_by_page` N = 64 / 1024 / 16384: "
+      f"{_f['group_indices_by_page_N64_us']:.1f} / {_f['group_indices_by_page_N1024_us']:.0f} / {_f['group_indices_by_page_N16384_us']:.0f} µs [1.3 / 16.8 / 292; on one host this library and the reference are level: `tests/perf_bookkeeping.py`]; "
+      f"fast path `alloc(k)+free`, k = 1 / 16 / 256: {_f['alloc(1)+free_us']:.1f} / {_f['alloc(16)+free_us']:.1f} / {_f['alloc(256)+free_us']:.1f} µs; "
+      f"`alloc(16)+free` from 1 / 4 / 8 threads: {_f['alloc(16)+free_1_threads_Kops']:.0f} / {_f['alloc(16)+free_4_threads_Kops']:.0f} / {_f['alloc(16)+free_8_threads_Kops']:.0f} Kops/s [41 / 49 / 52]; "
+      f"**slow path** (no reserved pages: every alloc backs fresh page ids of 32 slots and every free gives them back, both invalidations included) "
+      f"`alloc(k)+free`, k = 128 / 1024 / 4096: **{_s['alloc(128)+free_us'] / 1e3:.2f} / {_s['alloc(1024)+free_us'] / 1e3:.2f} / {_s['alloc(4096)+free_us'] / 1e3:.2f} ms** "
+      f"[4.0 / 32.5 / 134.4 ms for the alloc alone] = {_s['alloc(128)_us_per_2MiB_slot_(map+unmap)']:.1f} / {_s['alloc(1024)_us_per_2MiB_slot_(map+unmap)']:.1f} / {_s['alloc(4096)_us_per_2MiB_slot_(map+unmap)']:.1f} µs per 2 MiB slot mapped and unmapped (`profiles/r03_bench_alloc.jsonl`).")
 block = f'''**Round-3 numbers** (MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5`; committed run
 `profiles/r03_bench_n1.json`: on this box one TLB invalidation takes {d['tlb_shootdown_us'] / 1000:.2f} ms; over the boxes of the day 0.16–0.26, and the
 numbers move with it — a run on a box with a 0.16 ms invalidation is quoted in brackets; kernels and library were the same). What
@@ -40,6 +48,8 @@ next to it in the line:
 `compact_blocks` (every XCD inside its own eighth of the regions, §5): {rc['achieved'] / 1000:.2f} TB/s = **{rc['frac']:.3f} of peak** on random moves, {rc.get('planner_moves_GBps', 0) / 1000:.2f} on planner-ordered ones; the
 contiguous 2 GiB → 2 GiB copy of the same session through the same kernel: {rc['copy_ceiling_GBps'] / 1000:.2f}; torch's D2D copy: {rc['torch_d2d_copy_GBps'] / 1000:.2f}
 (`rocprofv3` + PMC of this kernel: `profiles/r03_compact_traffic.json`).
+The reference's own `benchmarks/bench_alloc` protocol restated (`benchmarks/bench_alloc.py`, cfg-1 geometry: 16 layers, 65536 blocks of 16 tokens; the
+reference's published numbers are from a GB10, BASELINE.md §2): {ba}
 Configs 2–4 in full and the soaks of the final library: `profiles/r03_bench_vmm.jsonl`, `r03_bench_elastic.jsonl`,
 `r03_bench_tp_ipc.jsonl`, `r03_soak.jsonl`, `r03_soak_long.jsonl` (§4.11, §7).
 
