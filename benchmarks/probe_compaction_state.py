@@ -12,6 +12,11 @@ import numpy as np  # noqa: E402
 from kvcached_amd import capi  # noqa: E402
 
 PAGE, block, n_blocks, regions, moves = 2 << 20, 32 * 1024, 4096, 64, 2048
+ballast = None
+if os.environ.get("KVC_PROBE_BALLAST_GIB"):      # hold that much device memory first: the library's buffers come from elsewhere
+    import torch
+    ballast = torch.empty(int(os.environ["KVC_PROBE_BALLAST_GIB"]) << 30, dtype=torch.int8, device="cuda:0")
+    torch.cuda.synchronize()
 capi.init("cuda:0", PAGE, False)
 capi.create_kv_tensors(2 * n_blocks * block, 1, "cuda:0", regions // 2, 2, 0, False)
 capi.map_to_kv_tensors([p * PAGE for p in range(n_blocks * block // PAGE)])
@@ -26,6 +31,6 @@ for _ in range(4):
     capi.compact_blocks(bases, src, dst, block, sync=False)
 capi.compact_blocks(bases[:1], src[:1], dst[:1], block, sync=True)
 st = capi.get_stats()
-print(json.dumps({"GBps": round(st["compact_bytes"] / st["compact_ms"] / 1e6)}), flush=True)
+print(json.dumps({"ballast_GiB": int(os.environ.get("KVC_PROBE_BALLAST_GIB", "0")), "GBps": round(st["compact_bytes"] / st["compact_ms"] / 1e6)}), flush=True)
 capi.unmap_from_kv_tensors([p * PAGE for p in range(n_blocks * block // PAGE)])
 capi.shutdown()
