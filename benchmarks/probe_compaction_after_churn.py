@@ -3,7 +3,7 @@
 bench's own variants do (a default cycle, a 48 GiB growth burst, a cycle with one buffer per page). Shows how much of the leg's
 rate is a property of where the driver places the library's buffers.
 
-    [KVCACHED_KFD_CONTIGUOUS=true] python benchmarks/probe_compaction_after_churn.py
+    python benchmarks/probe_compaction_after_churn.py
 """
 import json
 import os
@@ -17,8 +17,7 @@ from kvcached_amd import capi  # noqa: E402
 
 def leg(label):
     r = bench.compaction_roofline(capi, "cuda:0")
-    print(json.dumps({"when": label, "kfd_contiguous": os.environ.get("KVCACHED_KFD_CONTIGUOUS", "false"),
-                      "random_GBps": r["achieved"], "planner_GBps": r["planner_moves_GBps"], "on_torch_buffers_GBps": r["on_torch_buffers_GBps"],
+    print(json.dumps({"when": label, "random_GBps": r["achieved"], "planner_GBps": r["planner_moves_GBps"], "on_torch_buffers_GBps": r["on_torch_buffers_GBps"],
                       "contiguous_copy_GBps": r["copy_ceiling_GBps"]}), flush=True)
 
 

@@ -330,19 +330,8 @@ public:
     a.size = size;
     a.gpu_id = gpu_id_;
     a.flags = kKfdVramFlags;
-    // KVCACHED_KFD_CONTIGUOUS=true asks for physically contiguous VRAM, best effort (KFD_IOC_ALLOC_MEM_FLAGS_CONTIGUOUS, kernels that
-    // know the flag; one that does not refuses it with EINVAL once and is not asked again). A/B switch: DESIGN.md §5.
-    static std::atomic<int> contiguous{env_bool("KVCACHED_KFD_CONTIGUOUS", false) ? 1 : 0};
-    const bool ask = contiguous.load() == 1 && size > (2u << 20);
-    if (ask) a.flags |= kKfdContiguous;
     const int64_t t0 = now_ns();
-    int rc = kfd_ioctl(kKfdAlloc, &a);
-    if (rc != 0 && ask && errno == EINVAL) {
-      contiguous.store(0);
-      a.flags = kKfdVramFlags;
-      rc = kfd_ioctl(kKfdAlloc, &a);
-    }
-    if (rc != 0)
+    if (kfd_ioctl(kKfdAlloc, &a) != 0)
       throw GpuError(std::string("AMDKFD_IOC_ALLOC_MEMORY_OF_GPU failed: ") + (errno == ENOMEM ? "out of memory" : strerror(errno)));
     const int64_t t1 = now_ns();
     KfdExport e{};
@@ -516,7 +505,6 @@ private:
   // VRAM | WRITABLE | PUBLIC | NO_SUBSTITUTE, va 0: exactly what ROCr passes for hsa_amd_vmem_handle_create on the
   // coarse-grained device pool (its calls logged by tools/kfd_alloc_probe.cpp, profiles/r01_kfd_alloc_probe.log)
   static constexpr uint32_t kKfdVramFlags = (1u << 31) | (1u << 29) | (1u << 28) | 1u;
-  static constexpr uint32_t kKfdContiguous = 1u << 23; // KFD_IOC_ALLOC_MEM_FLAGS_CONTIGUOUS (best effort)
   int kfd_ioctl(unsigned long req, void *arg) {
     int r;
     do r = (int)syscall(SYS_ioctl, kfd_fd_, req, arg);
